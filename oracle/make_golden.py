@@ -1,0 +1,89 @@
+"""TEST INFRASTRUCTURE ONLY.  Generates tests/golden/*.npz by running the REFERENCE'S OWN PYTHON
+(/root/reference, via oracle/ref_shim.py) on seeded synthetic weights and inputs.
+
+Run in the build container only:   python -m oracle.make_golden
+The fixtures travel to the GPU box; the reference does not.
+
+Cases (weights: patchfusion_amd.spec.synthetic_state_dict(seed=0); image: torch.rand with
+Generator().manual_seed(1234); python `random` seeded 5621 before every forward, like
+tools/test.py:122-123 fix_random_seed):
+  tiny_vits : DA-vits, process 112x154, raw 448x616, split 2x2, process_num=2, modes m1 / m2 / r4,
+              full output maps + coarse depth + sampled coarse features
+  full_vits : DA-vits, process 392x518, raw 784x1036, split 2x2, process_num=4, mode m1, 8192
+              sampled output values + stats (kept small)
+"""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_shim  # noqa: E402
+from patchfusion_amd.config import make_config  # noqa: E402
+from patchfusion_amd.spec import patchfusion_spec, synthetic_state_dict  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def sample_idx(n, k, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(0, n, (k,), generator=g).numpy()
+
+
+def build(enc, ps, raw, split):
+    PF = ref_shim.import_reference()
+    cfg = make_config(enc, ps, raw, split)
+    with ref_shim.in_reference_cwd():
+        m = PF(cfg).eval()
+    sd = synthetic_state_dict(patchfusion_spec(cfg), 0)
+    print(m.load_state_dict(sd, strict=True))
+    img = torch.rand(1, 3, *raw, generator=torch.Generator().manual_seed(1234))
+    return m, cfg, img
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(os.cpu_count())
+    # ---------------- tiny ----------------
+    m, cfg, img = build("vits", (112, 154), (448, 616), (2, 2))
+    lr = m.resizer(img)
+    out = {}
+    with torch.no_grad():
+        cd, cf = m.coarse_forward(lr)
+        out["coarse_depth"] = cd.numpy()
+        for i, f in enumerate(cf):
+            flat = f.flatten()
+            idx = sample_idx(flat.numel(), 2048, 100 + i)
+            out[f"coarse_feat{i}_idx"] = idx
+            out[f"coarse_feat{i}_val"] = flat[idx].numpy()
+            out[f"coarse_feat{i}_stats"] = np.array([f.mean().item(), f.std().item(), f.abs().max().item()], np.float32)
+        for mode in ("m1", "m2", "r4"):
+            random.seed(5621)
+            d, _ = m(mode="infer", image_lr=lr, image_hr=img, cai_mode=mode, process_num=2)
+            out[f"depth_{mode}"] = d[0, 0].numpy()
+    np.savez_compressed(os.path.join(OUT, "tiny_vits.npz"), **out)
+    print("tiny_vits done", {k: v.shape for k, v in out.items() if k.startswith("depth")})
+    # ---------------- full-size vits ----------------
+    m, cfg, img = build("vits", (392, 518), (784, 1036), (2, 2))
+    lr = m.resizer(img)
+    out = {}
+    with torch.no_grad():
+        random.seed(5621)
+        cd, cf = m.coarse_forward(lr)
+        d, _ = m(mode="infer", image_lr=lr, image_hr=img, cai_mode="m1", process_num=4)
+    for name, t in (("coarse_depth", cd), ("depth_m1", d)):
+        flat = t.flatten()
+        idx = sample_idx(flat.numel(), 8192, 7)
+        out[name + "_idx"] = idx
+        out[name + "_val"] = flat[idx].numpy()
+        out[name + "_stats"] = np.array([t.mean().item(), t.std().item(), t.min().item(), t.max().item()], np.float32)
+    np.savez_compressed(os.path.join(OUT, "full_vits.npz"), **out)
+    print("full_vits done", out["depth_m1_stats"])
+
+
+if __name__ == "__main__":
+    main()

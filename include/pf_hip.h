@@ -1,0 +1,151 @@
+/* C ABI of libpf_hip.so -- the MI355X (gfx950) kernels behind PatchFusion's tiled-inference hot path.
+ *
+ * Plain pointers and sizes only (no torch types).  Every entry point launches asynchronously on
+ * the hipStream_t passed as `stream` (a void*), borrows the device pointers for the duration of
+ * the call and returns an int status (PF_OK = 0; message via pf_last_error()).  The Python host
+ * (patchfusion_amd/hip_ops.py) binds these with ctypes; INTEGRATION.md shows the stub a reference
+ * maintainer would add.  Each group cites the reference interface (file:line under the reference
+ * repo) whose stock PyTorch / torchvision / cuDNN op it replaces.
+ *
+ * dtype: 0 = float32 activations + f32-input MFMA ("exact"), 1 = bf16 activations + bf16 MFMA with
+ * f32 accumulation ("fast").  All activation tensors are NHWC with an explicit pixel stride `ld`
+ * (elements) so producers write directly into channel slices of concat buffers.
+ */
+#ifndef PF_HIP_H
+#define PF_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PF_DTYPE_F32 0
+#define PF_DTYPE_BF16 1
+
+#define PF_ACT_NONE 0
+#define PF_ACT_RELU 1
+#define PF_ACT_GELU 2      /* exact erf GELU (nn.GELU default) */
+#define PF_ACT_SOFTPLUS 3  /* nn.Softplus(beta=1, threshold=20) */
+
+const char* pf_last_error(void);
+int pf_version(void);
+
+/* ---- implicit-GEMM convolution / linear layer on the matrix cores --------------------------
+ * y[b,oy,ox,n] = epi( sum_{ky,kx,c} x[b, oy*stride-pad+ky, ox*stride-pad+kx, c] * w[n,ky,kx,c] )
+ * epi(v) = (act(v + bias[n]) * scale[n]) + res[...] + res2[...]
+ * Replaces: F.conv2d / nn.Linear / nn.ConvTranspose2d(k==s) + fused bias/ReLU/GELU/LayerScale/
+ * residual everywhere on the path: dinov2/layers/attention.py:51,60, mlp.py:35-41, block.py:82-107,
+ * patch_embed.py:76, depth_anything/dpt.py:30-63,87-95, blocks.py:53-59,117,
+ * zoedepth layers localbins_layers.py:87-92,112-116, attractor.py:156-161, dist_layers.py:88-95,
+ * estimator/models/patchfusion.py:121-127, blocks/guided_fusion_model.py:41-48,59-66,
+ * blocks/swin_layers.py:39-41,125-127.
+ * Weights are pre-packed by the host as [w_rows][Kpad] (K order = ky,kx,c; zero padded), in `dtype`.
+ */
+typedef struct {
+  const void* x; int x_ld; int B, H, W, Cin; /* Cin: valid input channels, multiple of 8 (zero weights on pad) */
+  const void* w; int w_rows; int Kpad;      /* Kpad multiple of 64 (bf16) / 32 (f32) elements */
+  const float* bias; const float* scale;    /* [Cout] or NULL (indexed by output channel) */
+  const void* res; int res_ld; const void* res2; int res2_ld; /* residual(s), NHWC like y, or NULL */
+  void* y; int y_ld; int OH, OW, Cout;      /* Cout: GEMM N = channels stored, multiple of 4 */
+  int KH, KW, stride, pad;
+  int act;       /* PF_ACT_* */
+  int relu_in;   /* apply ReLU to x on load (ResidualConvUnit, blocks.py:78,83) */
+  int out_f32;   /* store float32 even when dtype == bf16 (bins-head tensors) */
+  int shuffle;   /* s>1: ConvTranspose2d(kernel=stride=s): N = s*s*Cout_t, y is [B,OH*s,OW*s,Cout_t] */
+  int dtype;
+} pf_conv_params;
+int pf_conv(const pf_conv_params* p, void* stream);
+/* timing helper for the roofline entry of bench.py: runs `iters` launches bracketed by HIP events on
+ * `stream`, returns the average milliseconds per launch in *ms */
+int pf_conv_timed(const pf_conv_params* p, int iters, float* ms, void* stream);
+
+/* ---- ViT encoder pieces ---------------------------------------------------------------------- */
+/* (x - mean)/std + 14x14/14 patch gather: NCHW float image -> im2col rows [B*th*tw][ld] (K order
+ * ky,kx,c).  Replaces depth_anything.py:184-190 (Normalize) + the unfold implied by patch_embed.py:76 */
+int pf_patch_im2col(const float* img, int B, int H, int W, void* out, int ld, int dtype, void* stream);
+/* tokens[b,0,:] = cls + pos[0]; tokens[b,1+t,:] = emb[b*(S-1)+t,:] + pos[1+t]  (vision_transformer.py:222-223) */
+int pf_assemble_tokens(const void* emb, void* tokens, const float* cls, const float* pos, int B, int S, int D, int dtype,
+                       void* stream);
+/* LayerNorm over the last dim: y[r] = (x[r]-mu)/sqrt(var+eps)*g+b.  Rows are remapped so that the
+ * final `norm` + cls drop of get_intermediate_layers (vision_transformer.py:309-312) is one pass:
+ * out row (b, t) <- in row b*in_rows_per_batch + in_row_offset + t, t < out_rows_per_batch. */
+int pf_layernorm(const void* x, int x_ld, void* y, int y_ld, const float* g, const float* b, float eps,
+                 int batches, int in_rows_per_batch, int in_row_offset, int out_rows_per_batch, int D,
+                 int dtype, void* stream);
+/* split the fused qkv rows [B*S][3*D] into per-head Q*scale [B,H,S,64], K [B,H,S,64], V^T [B,H,64,Sp] */
+int pf_qkv_split(const void* qkv, int B, int S, int Hh, void* q, void* k, void* vt, int Sp, float scale,
+                 int dtype, void* stream);
+/* softmax(q k^T) v per (batch, head), head_dim 64, flash-style on the matrix cores; out [B*S][D].
+ * Replaces dinov2/layers/attention.py:53-59 (the materialised N x N scores). */
+int pf_vit_attention(const void* q, const void* k, const void* vt, void* out, int B, int S, int Sp, int Hh,
+                     int dtype, void* stream);
+
+/* ---- G2L (Swin window attention) -------------------------------------------------------------- */
+/* LayerNorm(norm1) -> zero pad to a multiple of 12 -> cyclic shift -> window partition
+ * (swin_layers.py:223-244): x [B,H,W,C] tokens -> xw [B*nW*144][C] */
+int pf_swin_ln_partition(const void* x, int x_ld, void* xw, const float* g, const float* b, float eps,
+                         int B, int H, int W, int C, int shift, int dtype, void* stream);
+/* window attention with relative-position bias and shift mask (swin_layers.py:133-164,327-345);
+ * qkv [B*nW*144][3C] -> out [B*nW*144][C]; bias_table [529][heads] float */
+int pf_swin_window_attention(const void* qkv, void* out, const float* bias_table, int B, int Hp, int Wp,
+                             int C, int heads, int shift, int dtype, void* stream);
+/* window reverse + un-shift + crop + residual (swin_layers.py:250-263): y = shortcut + proj[win(tok)] */
+int pf_swin_unpartition_add(const void* proj, const void* shortcut, int s_ld, void* y, int y_ld, int B, int H,
+                            int W, int C, int shift, int dtype, void* stream);
+/* x[b,t,:] += pos[t,:]  (absolute_pos_embed, swin_layers.py:419-420); pos float [T][C] */
+int pf_add_rowwise(void* x, int x_ld, const float* pos, int B, int T, int C, int dtype, void* stream);
+
+/* ---- memory-bound image ops --------------------------------------------------------------------- */
+/* bilinear, align_corners=True (F.interpolate; used at dpt.py:126,154, blocks.py:147,
+ * attractor.py:179,186, zoedepth_v1.py:204-214, guided_fusion_model.py:97,192).
+ * y[b,oy,ox, 0..C) = (add ? add[...] : 0) + interp(x).  NHWC both sides. */
+int pf_resize_bilinear(const void* x, int x_ld, int B, int H, int W, int C, void* y, int y_ld, int OH, int OW,
+                       const void* add, int add_ld, int in_f32, int out_f32, int dtype, void* stream);
+/* planar float version for the image crops (depth_anything/transform.py:127-129 applied per tile,
+ * baseline_pretrain.py:258-264): img [3][H][W] float -> out [P][3][oh][ow] float; boxes int [P][4]=(x0,y0,x1,y1) */
+int pf_crop_resize_planar(const float* img, int C, int H, int W, const int* boxes, int P, float* out, int oh, int ow,
+                          void* stream);
+/* torchvision.ops.roi_align(aligned=True, sampling_ratio=-1) (patchfusion.py:247,251;
+ * guided_fusion_model.py:202). feat [Bf,H,W,C] NHWC; rois float [K][5] = (batch, x1,y1,x2,y2);
+ * out [K,oh,ow,C] (ld y_ld).  in_f32/out_f32 select float storage for the depth map. */
+int pf_roi_align(const void* feat, int f_ld, int Bf, int H, int W, int C, const float* rois, int K, void* y,
+                 int y_ld, int oh, int ow, float spatial_scale, int in_f32, int out_f32, int dtype, void* stream);
+/* nn.MaxPool2d(2) (guided_fusion_model.py:78) */
+int pf_maxpool2(const void* x, int x_ld, int B, int H, int W, int C, void* y, int y_ld, int dtype, void* stream);
+/* channel-slice copy y[..., 0..C) = x[..., 0..C) with optional dtype change */
+int pf_copy_channels(const void* x, int x_ld, void* y, int y_ld, long npix, int C, int in_f32, int out_f32,
+                     int dtype, void* stream);
+/* fusion-net input cat[coarse_depth_roi, fine_depth, rgb crop] (patchfusion.py:269) -> [B,h,w,8] (3 zero pad) */
+int pf_pack_fusion_input(const float* cdepth, const float* fdepth, const float* crops, void* y, int B, int h, int w,
+                         int dtype, void* stream);
+/* NHWC (ld) <-> NCHW float converters for the module boundary */
+int pf_nhwc_to_nchw_f32(const void* x, int x_ld, float* y, int B, int H, int W, int C, int in_f32, int dtype, void* stream);
+
+/* ---- metric-bins head ----------------------------------------------------------------------------- */
+/* AttractorLayerUnnormed (attractor.py:164-208, inv attractor alpha=300 gamma=2, kind='mean'):
+ * c = bilinear_up(b_prev); out = c + mean_a( (A_a - c) / (1 + 300 (A_a - c)^2) ).  All float. */
+int pf_attractor(const float* A, int a_ld, int n_attr, const float* b_prev, int hp, int wp, float* out, int B, int h,
+                 int w, int n_bins, void* stream);
+/* ConditionalLogBinomial tail + expectation (dist_layers.py:29-33,51-69,108-121, zoedepth_v1.py:215-219):
+ * pt [B,h,w,4] float = softplus(mlp) ; centers [B,hc,wc,n_bins] float ; depth [B,h,w] float */
+int pf_logbinom_depth(const float* pt, int pt_ld, const float* centers, int hc, int wc, float* depth, int B, int h,
+                      int w, int n_bins, float min_temp, float max_temp, void* stream);
+
+/* ---- stitching (estimator/models/utils.py:21-36, baseline_pretrain.py:310-329,205-216) ------------ */
+/* init pass: pred[y0+i,x0+j] = depth*mask ; count[...] = mask  (P tiles) */
+int pf_stitch_init(float* pred, float* count, int MH, int MW, const float* depth, const float* mask, const int* yx,
+                   int P, int ph, int pw, void* stream);
+int pf_stitch_finish_init(float* avg, const float* pred, const float* count, long n, void* stream);
+/* RunningAverageMap.update restricted to the tile's footprint, tiles applied in order.
+ * depth tile is [dh][dw]; when (dh,dw) != (ph,pw) it is nearest-resized (F.interpolate default,
+ * baseline_pretrain.py:203) on the fly. */
+int pf_stitch_update(float* avg, float* count, int MH, int MW, const float* depth, int dh, int dw, const float* mask,
+                     int y0, int x0, int ph, int pw, void* stream);
+/* RunningAverageMap.resize: avg nearest, count bilinear align_corners */
+int pf_resize_nearest_f32(const float* x, int H, int W, float* y, int OH, int OW, void* stream);
+int pf_resize_bilinear_f32(const float* x, int H, int W, float* y, int OH, int OW, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,89 @@
+"""ctypes binding of libpf_hip.so (the C ABI declared in include/pf_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is absent the
+import of :mod:`patchfusion_amd.hip_ops` raises.  Build with ``python __graft_entry__.py`` or
+``make -C patchfusion_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpf_hip.so")
+
+vp, ci, cf, cl = C.c_void_p, C.c_int, C.c_float, C.c_long
+
+
+class ConvParams(C.Structure):
+    _fields_ = [
+        ("x", vp), ("x_ld", ci), ("B", ci), ("H", ci), ("W", ci), ("Cin", ci),
+        ("w", vp), ("w_rows", ci), ("Kpad", ci),
+        ("bias", vp), ("scale", vp),
+        ("res", vp), ("res_ld", ci), ("res2", vp), ("res2_ld", ci),
+        ("y", vp), ("y_ld", ci), ("OH", ci), ("OW", ci), ("Cout", ci),
+        ("KH", ci), ("KW", ci), ("stride", ci), ("pad", ci),
+        ("act", ci), ("relu_in", ci), ("out_f32", ci), ("shuffle", ci), ("dtype", ci),
+    ]
+
+
+# name -> argtypes (every function returns int status except pf_last_error / pf_version)
+SIGNATURES = {
+    "pf_conv": [C.POINTER(ConvParams), vp],
+    "pf_conv_timed": [C.POINTER(ConvParams), ci, C.POINTER(cf), vp],
+    "pf_patch_im2col": [vp, ci, ci, ci, vp, ci, ci, vp],
+    "pf_assemble_tokens": [vp, vp, vp, vp, ci, ci, ci, ci, vp],
+    "pf_layernorm": [vp, ci, vp, ci, vp, vp, cf, ci, ci, ci, ci, ci, ci, vp],
+    "pf_qkv_split": [vp, ci, ci, ci, vp, vp, vp, ci, cf, ci, vp],
+    "pf_vit_attention": [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
+    "pf_swin_ln_partition": [vp, ci, vp, vp, vp, cf, ci, ci, ci, ci, ci, ci, vp],
+    "pf_swin_window_attention": [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp],
+    "pf_swin_unpartition_add": [vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp],
+    "pf_add_rowwise": [vp, ci, vp, ci, ci, ci, ci, vp],
+    "pf_resize_bilinear": [vp, ci, ci, ci, ci, ci, vp, ci, ci, ci, vp, ci, ci, ci, ci, vp],
+    "pf_crop_resize_planar": [vp, ci, ci, ci, vp, ci, vp, ci, ci, vp],
+    "pf_roi_align": [vp, ci, ci, ci, ci, ci, vp, ci, vp, ci, ci, ci, cf, ci, ci, ci, vp],
+    "pf_maxpool2": [vp, ci, ci, ci, ci, ci, vp, ci, ci, vp],
+    "pf_copy_channels": [vp, ci, vp, ci, cl, ci, ci, ci, ci, vp],
+    "pf_pack_fusion_input": [vp, vp, vp, vp, ci, ci, ci, ci, vp],
+    "pf_nhwc_to_nchw_f32": [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp],
+    "pf_attractor": [vp, ci, ci, vp, ci, ci, vp, ci, ci, ci, ci, vp],
+    "pf_logbinom_depth": [vp, ci, vp, ci, ci, vp, ci, ci, ci, ci, cf, cf, vp],
+    "pf_stitch_init": [vp, vp, ci, ci, vp, vp, vp, ci, ci, ci, vp],
+    "pf_stitch_finish_init": [vp, vp, vp, cl, vp],
+    "pf_stitch_update": [vp, vp, ci, ci, vp, ci, ci, vp, ci, ci, ci, ci, vp],
+    "pf_resize_nearest_f32": [vp, ci, ci, vp, ci, ci, vp],
+    "pf_resize_bilinear_f32": [vp, ci, ci, vp, ci, ci, vp],
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library and bind every symbol of the C ABI; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python __graft_entry__.py` "
+            "(or `make -C patchfusion_amd/csrc`). There is no CPU fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.argtypes = args
+        fn.restype = ci
+    lib.pf_last_error.restype = C.c_char_p
+    lib.pf_last_error.argtypes = []
+    lib.pf_version.restype = ci
+    lib.pf_version.argtypes = []
+    _lib = lib
+    return lib
+
+
+class PfError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().pf_last_error()
+        raise PfError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,346 @@
+// Implicit-GEMM convolution / linear layer on the CDNA4 matrix cores (gfx950).
+//
+//   D[n][m] = sum_k W[n][k] * X[m][k]        n = output channel, m = output pixel, k = (ky,kx,c)
+//
+// The MFMA "A" operand is the WEIGHT tile and the "B" operand the ACTIVATION tile, so that a lane's
+// four accumulator registers are four CONSECUTIVE output channels of ONE pixel -> the NHWC epilogue
+// store is one 8-byte (bf16) / 16-byte (f32) vector per fragment.
+//
+// Tiling: 256 threads = 4 waves (WM x WN); block tile BM pixels x BN channels; every K step stages
+// one 128-byte row chunk per tile row (64 bf16 / 32 f32 elements) through registers into a 2-deep LDS
+// ring (one barrier per chunk, next chunk's global loads issued before the MFMAs of the current one).
+// LDS rows are 128 B; the 16-byte slot index is XOR-swizzled with (row>>1)&7 which makes every
+// ds_read_b128 lane group of the fragment reads hit 16 distinct slots (bank-conflict free, see
+// DESIGN.md "LDS swizzle").
+//
+// bf16: v_mfma_f32_16x16x32_bf16, lane (r=l&15, g=l>>4) holds k = g*8..g*8+7 of row r -> one 16-B slot.
+// f32 : v_mfma_f32_16x16x4_f32 (exact f32 FMA chain). A lane reads one float4 at slot g; element e of
+//       it feeds MFMA e, i.e. MFMA e contracts k in {4g+e}: a k-permutation applied identically to
+//       both operands, which leaves the sum unchanged.
+#include "pf_common.h"
+#include "../../include/pf_hip.h"
+
+namespace {
+
+template <typename T> __device__ __forceinline__ uint4 relu_vec(uint4 v);
+template <> __device__ __forceinline__ uint4 relu_vec<float>(uint4 v) {
+  v.x = (v.x & 0x80000000u) ? 0u : v.x; v.y = (v.y & 0x80000000u) ? 0u : v.y;
+  v.z = (v.z & 0x80000000u) ? 0u : v.z; v.w = (v.w & 0x80000000u) ? 0u : v.w;
+  return v;
+}
+__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t w) {
+  uint32_t neg = ((w >> 15) & 0x00010001u) * 0xffffu;
+  return w & ~neg;
+}
+template <> __device__ __forceinline__ uint4 relu_vec<bf16_t>(uint4 v) {
+  v.x = relu_bf16x2(v.x); v.y = relu_bf16x2(v.y); v.z = relu_bf16x2(v.z); v.w = relu_bf16x2(v.w);
+  return v;
+}
+
+template <typename T, int FM, int FN>
+__device__ __forceinline__ void mma_half(const uint4 (&wf)[FN], const uint4 (&xf)[FM], f32x4 (&acc)[FN][FM]);
+
+template <int FM, int FN>
+__device__ __forceinline__ void mma_half_bf16(const uint4 (&wf)[FN], const uint4 (&xf)[FM], f32x4 (&acc)[FN][FM]) {
+#pragma unroll
+  for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm)
+      acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[fn]),
+                                                            __builtin_bit_cast(bf16x8, xf[fm]), acc[fn][fm], 0, 0, 0);
+}
+template <int FM, int FN>
+__device__ __forceinline__ void mma_half_f32(const uint4 (&wf)[FN], const uint4 (&xf)[FM], f32x4 (&acc)[FN][FM]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm) {
+        const uint32_t a = e == 0 ? wf[fn].x : e == 1 ? wf[fn].y : e == 2 ? wf[fn].z : wf[fn].w;
+        const uint32_t b = e == 0 ? xf[fm].x : e == 1 ? xf[fm].y : e == 2 ? xf[fm].z : xf[fm].w;
+        acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a), __uint_as_float(b), acc[fn][fm], 0, 0, 0);
+      }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p) {
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int BK = 8 * VEC;  // elements per 128-byte chunk row
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int FM = WTM / 16, FN = WTN / 16;
+  constexpr int A_ITERS = (BM + 31) / 32, B_ITERS = (BN + 31) / 32;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(WTM % 16 == 0 && WTN % 16 == 0, "fragment multiple");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int OHW = p.OH * p.OW;
+  const int M = p.B * OHW;
+  const int nt = (p.Cout + BN - 1) / BN;
+  const int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int tile_m = bid / nt, tile_n = bid - tile_m * nt;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- loader state: thread -> (row r0 + 32 i, 16-byte slot j) ----
+  const int j = tid & 7, r0 = tid >> 3;
+  int a_iy0[A_ITERS], a_ix0[A_ITERS];
+  long a_base[A_ITERS];
+#pragma unroll
+  for (int i = 0; i < A_ITERS; ++i) {
+    const int m = m0 + r0 + 32 * i;
+    if (m < M && (r0 + 32 * i) < BM) {
+      const int b = m / OHW, rem = m - b * OHW;
+      const int oy = rem / p.OW, ox = rem - oy * p.OW;
+      a_iy0[i] = oy * p.stride - p.pad;
+      a_ix0[i] = ox * p.stride - p.pad;
+      a_base[i] = (long)b * p.H * p.W * p.x_ld;
+    } else {
+      a_iy0[i] = -(1 << 28);
+      a_ix0[i] = 0;
+      a_base[i] = 0;
+    }
+  }
+  const int cin_v = p.Cin / VEC;
+  const int ntaps = p.KH * p.KW;
+  const int nk = (ntaps * cin_v + 7) / 8;
+  const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
+
+  uint4 ra[A_ITERS], rb[B_ITERS];
+  auto gload = [&](int kc) {
+    const int kv = kc * 8 + j;
+    const int tap = kv / cin_v;
+    const int cv = kv - tap * cin_v;
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    const bool tap_ok = tap < ntaps;
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+      const bool ok = tap_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (ok) v = *reinterpret_cast<const uint4*>(xg + a_base[i] + ((long)iy * p.W + ix) * p.x_ld + cv * VEC);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i) {
+      const int rr = r0 + 32 * i;
+      const int row = n0 + rr;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (rr < BN && row < p.w_rows) v = *reinterpret_cast<const uint4*>(wg + (long)row * p.Kpad + (long)kc * BK + j * VEC);
+      rb[i] = v;
+    }
+  };
+  auto lstore = [&](int stage) {
+    char* As = smem + stage * STAGE;
+    char* Bs = As + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      const int rr = r0 + 32 * i;
+      if (rr < BM) {
+        uint4 v = ra[i];
+        if (p.relu_in) v = relu_vec<T>(v);
+        *reinterpret_cast<uint4*>(As + rr * 128 + ((j ^ ((rr >> 1) & 7)) << 4)) = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i) {
+      const int rr = r0 + 32 * i;
+      if (rr < BN) *reinterpret_cast<uint4*>(Bs + rr * 128 + ((j ^ ((rr >> 1) & 7)) << 4)) = rb[i];
+    }
+  };
+
+  f32x4 acc[FN][FM];
+#pragma unroll
+  for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) acc[fn][fm] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read addressing: lane (r, g); tile rows are multiples of 16 so the swizzle term is per-lane
+  const int fr = lane & 15, fg = lane >> 4;
+  const int swz = (fr >> 1) & 7;
+  const int a_row_off = (wm * WTM + fr) * 128;  // activations (pixels)
+  const int b_row_off = (wn * WTN + fr) * 128;  // weights (channels)
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int kc = 0; kc < nk; ++kc) {
+    const bool more = kc + 1 < nk;
+    if (more) gload(kc + 1);
+    const char* As = smem + (kc & 1) * STAGE;
+    const char* Bs = As + A_BYTES;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int slot = (((s << 2) | fg) ^ swz) << 4;
+      uint4 wf[FN], xf[FM];
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn) wf[fn] = *reinterpret_cast<const uint4*>(Bs + b_row_off + fn * 16 * 128 + slot);
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm) xf[fm] = *reinterpret_cast<const uint4*>(As + a_row_off + fm * 16 * 128 + slot);
+      if constexpr (sizeof(T) == 2) mma_half_bf16<FM, FN>(wf, xf, acc);
+      else mma_half_f32<FM, FN>(wf, xf, acc);
+    }
+    if (more) lstore((kc + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias -> act -> scale -> residual(s) -> store 4 consecutive channels ----
+  const int s = p.shuffle > 1 ? p.shuffle : 1;
+  const int cout_t = p.Cout / (s * s);
+#pragma unroll
+  for (int fm = 0; fm < FM; ++fm) {
+    const int m = m0 + wm * WTM + fm * 16 + fr;
+    if (m >= M) continue;
+    int b = 0, oy = 0, ox = 0;
+    if (s > 1) {
+      b = m / OHW;
+      const int rem = m - b * OHW;
+      oy = rem / p.OW;
+      ox = rem - oy * p.OW;
+    }
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) {
+      const int n = n0 + wn * WTN + fn * 16 + fg * 4;
+      if (n >= p.Cout) continue;
+      int co = n;
+      long opix = m;
+      if (s > 1) {
+        const int q = n / cout_t;
+        co = n - q * cout_t;
+        const int dy = q / s, dx = q - dy * s;
+        opix = ((long)b * (p.OH * s) + (oy * s + dy)) * (p.OW * s) + (ox * s + dx);
+      }
+      float v[4] = {acc[fn][fm][0], acc[fn][fm][1], acc[fn][fm][2], acc[fn][fm][3]};
+      if (p.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += p.bias[co + r];
+      }
+      if (p.act == PF_ACT_RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      } else if (p.act == PF_ACT_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+      } else if (p.act == PF_ACT_SOFTPLUS) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = softplus20(v[r]);
+      }
+      if (p.scale) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= p.scale[co + r];
+      }
+      if (p.res) {
+        float t[4];
+        load4(reinterpret_cast<const T*>(p.res) + opix * p.res_ld + co, t);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += t[r];
+      }
+      if (p.res2) {
+        float t[4];
+        load4(reinterpret_cast<const T*>(p.res2) + opix * p.res2_ld + co, t);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += t[r];
+      }
+      if (p.out_f32) store4(reinterpret_cast<float*>(p.y) + opix * p.y_ld + co, v[0], v[1], v[2], v[3]);
+      else store4(reinterpret_cast<T*>(p.y) + opix * p.y_ld + co, v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+thread_local char g_err[256] = {0};
+
+template <typename T, int BM, int BN, int WM, int WN>
+int launch_cfg(const pf_conv_params& p, hipStream_t st) {
+  constexpr int smem = 2 * (BM + BN) * 128;
+  static bool attr_set = false;
+  auto kern = conv_igemm_kernel<T, BM, BN, WM, WN>;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  const long M = (long)p.B * p.OH * p.OW;
+  const long mt = (M + BM - 1) / BM, nt = (p.Cout + BN - 1) / BN;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(mt * nt)), dim3(256), smem, st, p);
+  return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_LAUNCH;
+}
+
+template <typename T>
+int dispatch(const pf_conv_params& p, hipStream_t st) {
+  // pick the channel tile minimising padded work / tile efficiency
+  const int cand[5] = {128, 96, 64, 32, 16};
+  const float eff[5] = {1.0f, 0.97f, 0.9f, 0.8f, 0.6f};
+  int best = 0;
+  float best_cost = 1e30f;
+  for (int i = 0; i < 5; ++i) {
+    const int padded = (p.Cout + cand[i] - 1) / cand[i] * cand[i];
+    const float c = padded / eff[i];
+    if (c < best_cost) { best_cost = c; best = i; }
+  }
+  switch (cand[best]) {
+    case 128: return launch_cfg<T, 128, 128, 2, 2>(p, st);
+    case 96: return launch_cfg<T, 128, 96, 2, 2>(p, st);
+    case 64: return launch_cfg<T, 128, 64, 2, 2>(p, st);
+    case 32: return launch_cfg<T, 256, 32, 4, 1>(p, st);
+    default: return launch_cfg<T, 256, 16, 4, 1>(p, st);
+  }
+}
+
+int validate(const pf_conv_params* p) {
+  const int vec = p->dtype == PF_DTYPE_BF16 ? 8 : 4;
+  const int bk = 8 * vec;
+  const char* e = nullptr;
+  if (!p->x || !p->w || !p->y) e = "null tensor";
+  else if (p->dtype != PF_DTYPE_F32 && p->dtype != PF_DTYPE_BF16) e = "bad dtype";
+  else if (p->Cin <= 0 || p->Cin % vec) e = "Cin must be a positive multiple of the 16-byte vector";
+  else if (p->x_ld % vec || p->x_ld < p->Cin) e = "x_ld must be a multiple of the vector and >= Cin";
+  else if (p->Cout <= 0 || p->Cout % 4) e = "Cout must be a positive multiple of 4";
+  else if (p->y_ld % 4 || (p->res && p->res_ld % 4) || (p->res2 && p->res2_ld % 4)) e = "output/residual ld must be multiples of 4";
+  else if (p->Kpad % bk) e = "Kpad must be a multiple of the 128-byte chunk";
+  else if ((long)p->KH * p->KW * (p->Cin / vec) > (long)(p->Kpad / vec)) e = "Kpad smaller than KH*KW*Cin";
+  else if (p->w_rows < p->Cout) e = "w_rows < Cout";
+  else if (p->shuffle > 1 && (p->Cout % (p->shuffle * p->shuffle) || (p->Cout / (p->shuffle * p->shuffle)) % 4)) e = "shuffle: Cout/(s*s) must be a multiple of 4";
+  else if (p->shuffle > 1 && (p->KH != 1 || p->KW != 1 || p->res || p->res2)) e = "shuffle only for 1x1 without residual";
+  else if ((long)p->B * p->OH * p->OW <= 0) e = "empty output";
+  else if ((long)p->B * p->OH * p->OW >= (1L << 31)) e = "too many output pixels";
+  if (e) { snprintf(g_err, sizeof(g_err), "pf_conv: %s", e); return PF_ERR_ARG; }
+  return PF_OK;
+}
+
+}  // namespace
+
+extern "C" const char* pf_last_error(void) { return g_err; }
+extern "C" int pf_version(void) { return 1; }
+
+extern "C" int pf_conv(const pf_conv_params* p, void* stream) {
+  if (!p) return PF_ERR_ARG;
+  int rc = validate(p);
+  if (rc) return rc;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  rc = p->dtype == PF_DTYPE_BF16 ? dispatch<bf16_t>(*p, st) : dispatch<float>(*p, st);
+  if (rc) snprintf(g_err, sizeof(g_err), "pf_conv: launch failed: %s", hipGetErrorString(hipGetLastError()));
+  return rc;
+}
+
+extern "C" int pf_conv_timed(const pf_conv_params* p, int iters, float* ms, void* stream) {
+  if (!p || !ms || iters <= 0) return PF_ERR_ARG;
+  int rc = validate(p);
+  if (rc) return rc;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  rc = pf_conv(p, stream);  // warm-up
+  hipEventRecord(e0, st);
+  for (int i = 0; i < iters && rc == PF_OK; ++i) rc = pf_conv(p, stream);
+  hipEventRecord(e1, st);
+  hipEventSynchronize(e1);
+  float t = 0.f;
+  hipEventElapsedTime(&t, e0, e1);
+  *ms = t / iters;
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  return rc;
+}

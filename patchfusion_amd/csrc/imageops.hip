@@ -1,0 +1,511 @@
+// HBM-bound image kernels of the PatchFusion hot path: bilinear resize (align_corners=True),
+// per-tile crop+resize, roi_align, max-pool, channel-slice copy, fusion-net input packing, layout
+// conversion, the metric-bins head tail (attractor, log-binomial expectation) and the tile stitcher.
+// All loads/stores are 16-byte vectors over the contiguous channel axis of NHWC tensors.
+#include "pf_common.h"
+#include "../../include/pf_hip.h"
+
+namespace {
+
+inline int grid_for(long n, int block) {
+  long g = (n + block - 1) / block;
+  return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
+}
+inline int ok() { return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_LAUNCH; }
+
+// PyTorch upsample_bilinear2d, align_corners=True: scale = (in-1)/(out-1); src = scale*dst
+struct Lerp {
+  int i0, i1;
+  float l0, l1;
+};
+__device__ __forceinline__ Lerp ac_coord(int dst, float scale, int in) {
+  const float src = scale * dst;
+  Lerp r;
+  r.i0 = (int)src;
+  r.i1 = r.i0 + (r.i0 < in - 1 ? 1 : 0);
+  r.l1 = src - r.i0;
+  r.l0 = 1.0f - r.l1;
+  return r;
+}
+inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+template <typename T>
+__device__ __forceinline__ void ld8x(const void* p, long off, int f32, float (&v)[8]) {
+  if (f32) load8(reinterpret_cast<const float*>(p) + off, v);
+  else load8(reinterpret_cast<const T*>(p) + off, v);
+}
+template <typename T>
+__device__ __forceinline__ void st8x(void* p, long off, int f32, const float (&v)[8]) {
+  if (f32) store8(reinterpret_cast<float*>(p) + off, v);
+  else store8(reinterpret_cast<T*>(p) + off, v);
+}
+
+template <typename T>
+__global__ void resize_bilinear_kernel(const void* __restrict__ x, int x_ld, int B, int H, int W, int C, void* __restrict__ y,
+                                       int y_ld, int OH, int OW, const void* __restrict__ add, int add_ld, int in_f32,
+                                       int out_f32, float sh, float sw) {
+  const int cv = C >> 3;
+  const long total = (long)B * OH * OW * cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % cv);
+    long pix = i / cv;
+    const int ox = (int)(pix % OW);
+    const int oy = (int)((pix / OW) % OH);
+    const int b = (int)(pix / ((long)OW * OH));
+    const Lerp ly = ac_coord(oy, sh, H), lx = ac_coord(ox, sw, W);
+    const long base = (long)b * H * W;
+    float v00[8], v01[8], v10[8], v11[8], o[8];
+    ld8x<T>(x, (base + (long)ly.i0 * W + lx.i0) * x_ld + v * 8, in_f32, v00);
+    ld8x<T>(x, (base + (long)ly.i0 * W + lx.i1) * x_ld + v * 8, in_f32, v01);
+    ld8x<T>(x, (base + (long)ly.i1 * W + lx.i0) * x_ld + v * 8, in_f32, v10);
+    ld8x<T>(x, (base + (long)ly.i1 * W + lx.i1) * x_ld + v * 8, in_f32, v11);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = ly.l0 * (lx.l0 * v00[e] + lx.l1 * v01[e]) + ly.l1 * (lx.l0 * v10[e] + lx.l1 * v11[e]);
+    if (add) {
+      float a[8];
+      ld8x<T>(add, pix * add_ld + v * 8, out_f32, a);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = a[e] + o[e];
+    }
+    st8x<T>(y, pix * y_ld + v * 8, out_f32, o);
+  }
+}
+
+__global__ void crop_resize_planar_kernel(const float* __restrict__ img, int C, int H, int W, const int* __restrict__ boxes, int P,
+                                          float* __restrict__ out, int oh, int ow) {
+  const long total = (long)P * C * oh * ow;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % ow);
+    const int oy = (int)((i / ow) % oh);
+    const int c = (int)((i / ((long)ow * oh)) % C);
+    const int p = (int)(i / ((long)ow * oh * C));
+    const int x0 = boxes[p * 4 + 0], y0 = boxes[p * 4 + 1], bw = boxes[p * 4 + 2] - x0, bh = boxes[p * 4 + 3] - y0;
+    const float sh = oh > 1 ? (float)(bh - 1) / (float)(oh - 1) : 0.f;
+    const float sw = ow > 1 ? (float)(bw - 1) / (float)(ow - 1) : 0.f;
+    const Lerp ly = ac_coord(oy, sh, bh), lx = ac_coord(ox, sw, bw);
+    const float* src = img + (long)c * H * W;
+    const float v00 = src[(long)(y0 + ly.i0) * W + x0 + lx.i0], v01 = src[(long)(y0 + ly.i0) * W + x0 + lx.i1];
+    const float v10 = src[(long)(y0 + ly.i1) * W + x0 + lx.i0], v11 = src[(long)(y0 + ly.i1) * W + x0 + lx.i1];
+    out[i] = ly.l0 * (lx.l0 * v00 + lx.l1 * v01) + ly.l1 * (lx.l0 * v10 + lx.l1 * v11);
+  }
+}
+
+// torchvision roi_align, aligned=True, sampling_ratio=-1 (adaptive).  Coordinates follow the
+// torchvision kernel's float32 operation order; __f*_rn intrinsics forbid FMA contraction.
+template <typename T>
+__global__ void roi_align_kernel(const void* __restrict__ feat, int f_ld, int Bf, int H, int W, int C, const float* __restrict__ rois,
+                                 int K, void* __restrict__ y, int y_ld, int oh, int ow, float scale, int in_f32, int out_f32) {
+  const int cv = (C + 7) >> 3;
+  const long total = (long)K * oh * ow * cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % cv);
+    long pix = i / cv;
+    const int pw = (int)(pix % ow);
+    const int ph = (int)((pix / ow) % oh);
+    const int k = (int)(pix / ((long)ow * oh));
+    const float* r = rois + k * 5;
+    const int b = (int)r[0];
+    const float start_w = __fsub_rn(__fmul_rn(r[1], scale), 0.5f), start_h = __fsub_rn(__fmul_rn(r[2], scale), 0.5f);
+    const float end_w = __fsub_rn(__fmul_rn(r[3], scale), 0.5f), end_h = __fsub_rn(__fmul_rn(r[4], scale), 0.5f);
+    const float roi_w = __fsub_rn(end_w, start_w), roi_h = __fsub_rn(end_h, start_h);
+    const float bin_h = __fdiv_rn(roi_h, (float)oh), bin_w = __fdiv_rn(roi_w, (float)ow);
+    const int gh = (int)ceilf(__fdiv_rn(roi_h, (float)oh)), gw = (int)ceilf(__fdiv_rn(roi_w, (float)ow));
+    const float count = (float)max(gh * gw, 1);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int iy = 0; iy < gh; ++iy) {
+      float yy = __fadd_rn(__fadd_rn(start_h, __fmul_rn((float)ph, bin_h)), __fdiv_rn(__fmul_rn((float)iy + 0.5f, bin_h), (float)gh));
+      for (int ix = 0; ix < gw; ++ix) {
+        float xx = __fadd_rn(__fadd_rn(start_w, __fmul_rn((float)pw, bin_w)), __fdiv_rn(__fmul_rn((float)ix + 0.5f, bin_w), (float)gw));
+        float y2 = yy;
+        if (y2 < -1.0f || y2 > (float)H || xx < -1.0f || xx > (float)W) continue;
+        if (y2 <= 0.f) y2 = 0.f;
+        if (xx <= 0.f) xx = 0.f;
+        int yl = (int)y2, xl = (int)xx, yh, xh;
+        if (yl >= H - 1) { yh = yl = H - 1; y2 = (float)yl; } else yh = yl + 1;
+        if (xl >= W - 1) { xh = xl = W - 1; xx = (float)xl; } else xh = xl + 1;
+        const float ly = y2 - yl, lx = xx - xl, hy = 1.f - ly, hx = 1.f - lx;
+        const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+        const long base = (long)b * H * W;
+        float v1[8], v2[8], v3[8], v4[8];
+        ld8x<T>(feat, (base + (long)yl * W + xl) * f_ld + v * 8, in_f32, v1);
+        ld8x<T>(feat, (base + (long)yl * W + xh) * f_ld + v * 8, in_f32, v2);
+        ld8x<T>(feat, (base + (long)yh * W + xl) * f_ld + v * 8, in_f32, v3);
+        ld8x<T>(feat, (base + (long)yh * W + xh) * f_ld + v * 8, in_f32, v4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += w1 * v1[e] + w2 * v2[e] + w3 * v3[e] + w4 * v4[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] /= count;
+    st8x<T>(y, pix * y_ld + v * 8, out_f32, acc);
+  }
+}
+
+// single-channel float map (the coarse depth): same sampling, scalar loads
+__global__ void roi_align_scalar_kernel(const float* __restrict__ feat, int Bf, int H, int W, const float* __restrict__ rois, int K,
+                                        float* __restrict__ y, int oh, int ow, float scale) {
+  const long total = (long)K * oh * ow;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int pw = (int)(i % ow);
+    const int ph = (int)((i / ow) % oh);
+    const int k = (int)(i / ((long)ow * oh));
+    const float* r = rois + k * 5;
+    const int b = (int)r[0];
+    const float start_w = __fsub_rn(__fmul_rn(r[1], scale), 0.5f), start_h = __fsub_rn(__fmul_rn(r[2], scale), 0.5f);
+    const float end_w = __fsub_rn(__fmul_rn(r[3], scale), 0.5f), end_h = __fsub_rn(__fmul_rn(r[4], scale), 0.5f);
+    const float roi_w = __fsub_rn(end_w, start_w), roi_h = __fsub_rn(end_h, start_h);
+    const float bin_h = __fdiv_rn(roi_h, (float)oh), bin_w = __fdiv_rn(roi_w, (float)ow);
+    const int gh = (int)ceilf(__fdiv_rn(roi_h, (float)oh)), gw = (int)ceilf(__fdiv_rn(roi_w, (float)ow));
+    const float count = (float)max(gh * gw, 1);
+    const float* src = feat + (long)b * H * W;
+    float acc = 0.f;
+    for (int iy = 0; iy < gh; ++iy) {
+      const float yy0 = __fadd_rn(__fadd_rn(start_h, __fmul_rn((float)ph, bin_h)), __fdiv_rn(__fmul_rn((float)iy + 0.5f, bin_h), (float)gh));
+      for (int ix = 0; ix < gw; ++ix) {
+        float xx = __fadd_rn(__fadd_rn(start_w, __fmul_rn((float)pw, bin_w)), __fdiv_rn(__fmul_rn((float)ix + 0.5f, bin_w), (float)gw));
+        float y2 = yy0;
+        if (y2 < -1.0f || y2 > (float)H || xx < -1.0f || xx > (float)W) continue;
+        if (y2 <= 0.f) y2 = 0.f;
+        if (xx <= 0.f) xx = 0.f;
+        int yl = (int)y2, xl = (int)xx, yh, xh;
+        if (yl >= H - 1) { yh = yl = H - 1; y2 = (float)yl; } else yh = yl + 1;
+        if (xl >= W - 1) { xh = xl = W - 1; xx = (float)xl; } else xh = xl + 1;
+        const float ly = y2 - yl, lx = xx - xl, hy = 1.f - ly, hx = 1.f - lx;
+        acc += hy * hx * src[(long)yl * W + xl] + hy * lx * src[(long)yl * W + xh] + ly * hx * src[(long)yh * W + xl] + ly * lx * src[(long)yh * W + xh];
+      }
+    }
+    y[i] = acc / count;
+  }
+}
+
+template <typename T>
+__global__ void maxpool2_kernel(const T* __restrict__ x, int x_ld, int B, int H, int W, int C, T* __restrict__ y, int y_ld) {
+  const int OH = H / 2, OW = W / 2, cv = C >> 3;
+  const long total = (long)B * OH * OW * cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % cv);
+    long pix = i / cv;
+    const int ox = (int)(pix % OW);
+    const int oy = (int)((pix / OW) % OH);
+    const int b = (int)(pix / ((long)OW * OH));
+    const long base = ((long)b * H + 2 * oy) * W + 2 * ox;
+    float a[8], t[8];
+    load8(x + base * x_ld + v * 8, a);
+    load8(x + (base + 1) * x_ld + v * 8, t);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = fmaxf(a[e], t[e]);
+    load8(x + (base + W) * x_ld + v * 8, t);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = fmaxf(a[e], t[e]);
+    load8(x + (base + W + 1) * x_ld + v * 8, t);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = fmaxf(a[e], t[e]);
+    store8(y + pix * y_ld + v * 8, a);
+  }
+}
+
+template <typename T>
+__global__ void copy_channels_kernel(const void* __restrict__ x, int x_ld, void* __restrict__ y, int y_ld, long npix, int C,
+                                     int in_f32, int out_f32) {
+  const int cv = C >> 3;
+  const long total = npix * cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % cv);
+    const long pix = i / cv;
+    float a[8];
+    ld8x<T>(x, pix * x_ld + v * 8, in_f32, a);
+    st8x<T>(y, pix * y_ld + v * 8, out_f32, a);
+  }
+}
+
+template <typename T>
+__global__ void pack_fusion_input_kernel(const float* __restrict__ cd, const float* __restrict__ fd, const float* __restrict__ crops,
+                                         T* __restrict__ y, int B, int h, int w) {
+  const long hw = (long)h * w, total = (long)B * hw;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / hw, p = i % hw;
+    float o[8] = {cd[i], fd[i], crops[(b * 3 + 0) * hw + p], crops[(b * 3 + 1) * hw + p], crops[(b * 3 + 2) * hw + p], 0.f, 0.f, 0.f};
+    store8(y + i * 8, o);
+  }
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const void* __restrict__ x, int x_ld, float* __restrict__ y, int B, int H, int W, int C, int in_f32) {
+  const long hw = (long)H * W, total = (long)B * C * hw;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long p = i % hw;
+    const int c = (int)((i / hw) % C);
+    const long b = i / (hw * C);
+    const long src = (b * hw + p) * x_ld + c;
+    y[i] = in_f32 ? reinterpret_cast<const float*>(x)[src] : Elem<T>::ld(reinterpret_cast<const T*>(x) + src);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// metric-bins head
+// ---------------------------------------------------------------------------------------------
+__global__ void attractor_kernel(const float* __restrict__ A, int a_ld, int n_attr, const float* __restrict__ bp, int hp, int wp,
+                                 float* __restrict__ out, int B, int h, int w, int n_bins, float sh, float sw) {
+  const int bv = n_bins >> 2;
+  const long total = (long)B * h * w * bv;
+  const float inv_n = 1.0f / (float)n_attr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % bv);
+    long pix = i / bv;
+    const int ox = (int)(pix % w);
+    const int oy = (int)((pix / w) % h);
+    const int b = (int)(pix / ((long)w * h));
+    const Lerp ly = ac_coord(oy, sh, hp), lx = ac_coord(ox, sw, wp);
+    const long base = (long)b * hp * wp;
+    float v00[4], v01[4], v10[4], v11[4], c[4], d[4];
+    load4(bp + (base + (long)ly.i0 * wp + lx.i0) * n_bins + v * 4, v00);
+    load4(bp + (base + (long)ly.i0 * wp + lx.i1) * n_bins + v * 4, v01);
+    load4(bp + (base + (long)ly.i1 * wp + lx.i0) * n_bins + v * 4, v10);
+    load4(bp + (base + (long)ly.i1 * wp + lx.i1) * n_bins + v * 4, v11);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      c[e] = ly.l0 * (lx.l0 * v00[e] + lx.l1 * v01[e]) + ly.l1 * (lx.l0 * v10[e] + lx.l1 * v11[e]);
+      d[e] = 0.f;
+    }
+    const float* a = A + pix * a_ld;
+    for (int k = 0; k < n_attr; ++k) {
+      const float ak = a[k];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float dx = ak - c[e];
+        d[e] += dx / (1.0f + 300.0f * (dx * dx));
+      }
+    }
+    store4(out + pix * n_bins + v * 4, c[0] + d[0] * inv_n, c[1] + d[1] * inv_n, c[2] + d[2] * inv_n, c[3] + d[3] * inv_n);
+  }
+}
+
+__global__ void logbinom_depth_kernel(const float* __restrict__ pt, int pt_ld, const float* __restrict__ cen, int hc, int wc,
+                                      float* __restrict__ depth, int B, int h, int w, int n_bins, float min_temp, float max_temp,
+                                      float sh, float sw) {
+  const long total = (long)B * h * w;
+  const float eps = 1e-7f;
+  const float n_ = (float)(n_bins - 1) + eps;
+  const float nlogn = n_ * logf(n_);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % w);
+    const int oy = (int)((i / w) % h);
+    const int b = (int)(i / ((long)w * h));
+    const float* q = pt + i * pt_ld;
+    const float p0 = q[0] + 1e-4f, p1 = q[1] + 1e-4f, t0 = q[2] + 1e-4f, t1 = q[3] + 1e-4f;
+    float p = p0 / (p0 + p1);
+    float t = t0 / (t0 + t1);
+    t = (max_temp - min_temp) * t + min_temp;
+    const float omp = fminf(fmaxf(1.0f - p, 1e-4f), 1.0f);
+    p = fminf(fmaxf(p, 1e-4f), 1.0f);
+    const float lp = logf(p), lq = logf(omp);
+    // pass 1: max_k y_k / t
+    float mx = -INFINITY;
+    for (int k = 0; k < n_bins; ++k) {
+      const float k_ = (float)k + eps;
+      const float logc = nlogn - k_ * logf(k_) - (n_ - k_) * logf(n_ - k_ + eps);
+      const float yk = (logc + (float)k * lp + (float)(n_bins - 1 - k) * lq) / t;
+      mx = fmaxf(mx, yk);
+    }
+    const Lerp ly = ac_coord(oy, sh, hc), lx = ac_coord(ox, sw, wc);
+    const long base = (long)b * hc * wc;
+    const float* c00 = cen + (base + (long)ly.i0 * wc + lx.i0) * n_bins;
+    const float* c01 = cen + (base + (long)ly.i0 * wc + lx.i1) * n_bins;
+    const float* c10 = cen + (base + (long)ly.i1 * wc + lx.i0) * n_bins;
+    const float* c11 = cen + (base + (long)ly.i1 * wc + lx.i1) * n_bins;
+    float num = 0.f, den = 0.f;
+    for (int k4 = 0; k4 < n_bins; k4 += 4) {
+      float a00[4], a01[4], a10[4], a11[4];
+      load4(c00 + k4, a00); load4(c01 + k4, a01); load4(c10 + k4, a10); load4(c11 + k4, a11);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = k4 + e;
+        const float k_ = (float)k + eps;
+        const float logc = nlogn - k_ * logf(k_) - (n_ - k_) * logf(n_ - k_ + eps);
+        const float yk = (logc + (float)k * lp + (float)(n_bins - 1 - k) * lq) / t;
+        const float pe = expf(yk - mx);
+        const float c = ly.l0 * (lx.l0 * a00[e] + lx.l1 * a01[e]) + ly.l1 * (lx.l0 * a10[e] + lx.l1 * a11[e]);
+        num += pe * c;
+        den += pe;
+      }
+    }
+    depth[i] = num / den;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// stitching
+// ---------------------------------------------------------------------------------------------
+__global__ void stitch_init_kernel(float* __restrict__ pred, float* __restrict__ count, int MH, int MW, const float* __restrict__ depth,
+                                   const float* __restrict__ mask, const int* __restrict__ yx, int P, int ph, int pw) {
+  const long total = (long)P * ph * pw;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % pw);
+    const int y = (int)((i / pw) % ph);
+    const int p = (int)(i / ((long)pw * ph));
+    const int Y = yx[2 * p] + y, X = yx[2 * p + 1] + x;
+    if (Y < MH && X < MW) {
+      const float m = mask[(long)y * pw + x];
+      pred[(long)Y * MW + X] = depth[i] * m;
+      count[(long)Y * MW + X] = m;
+    }
+  }
+}
+__global__ void div_kernel(float* __restrict__ avg, const float* __restrict__ pred, const float* __restrict__ count, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) avg[i] = pred[i] / count[i];
+}
+__global__ void stitch_update_kernel(float* __restrict__ avg, float* __restrict__ count, int MH, int MW, const float* __restrict__ depth,
+                                     int dh, int dw, const float* __restrict__ mask, int y0, int x0, int ph, int pw, float sy, float sx) {
+  const long total = (long)ph * pw;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % pw), y = (int)(i / pw);
+    const int Y = y0 + y, X = x0 + x;
+    if (Y >= MH || X >= MW) continue;
+    float d;
+    if (dh == ph && dw == pw) d = depth[i];
+    else {  // F.interpolate(mode='nearest'): src = min(floor(dst * in/out), in-1)
+      const int syi = min((int)floorf(y * sy), dh - 1), sxi = min((int)floorf(x * sx), dw - 1);
+      d = depth[(long)syi * dw + sxi];
+    }
+    const float m = mask[i];
+    const long o = (long)Y * MW + X;
+    const float c = count[o], a = avg[o];
+    avg[o] = (d * m + c * a) / (c + m);
+    count[o] = c + m;
+  }
+}
+__global__ void resize_nearest_kernel(const float* __restrict__ x, int H, int W, float* __restrict__ y, int OH, int OW, float sy, float sx) {
+  const long total = (long)OH * OW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW), oy = (int)(i / OW);
+    const int iy = min((int)floorf(oy * sy), H - 1), ix = min((int)floorf(ox * sx), W - 1);
+    y[i] = x[(long)iy * W + ix];
+  }
+}
+__global__ void resize_bilinear_f32_kernel(const float* __restrict__ x, int H, int W, float* __restrict__ y, int OH, int OW, float sh, float sw) {
+  const long total = (long)OH * OW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW), oy = (int)(i / OW);
+    const Lerp ly = ac_coord(oy, sh, H), lx = ac_coord(ox, sw, W);
+    const float v00 = x[(long)ly.i0 * W + lx.i0], v01 = x[(long)ly.i0 * W + lx.i1], v10 = x[(long)ly.i1 * W + lx.i0], v11 = x[(long)ly.i1 * W + lx.i1];
+    y[i] = ly.l0 * (lx.l0 * v00 + lx.l1 * v01) + ly.l1 * (lx.l0 * v10 + lx.l1 * v11);
+  }
+}
+
+}  // namespace
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+#define LAUNCH_T(kern, total, ...)                                                                                      \
+  do {                                                                                                                  \
+    if (dtype == PF_DTYPE_BF16) hipLaunchKernelGGL(kern<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, ST(stream), __VA_ARGS__); \
+    else hipLaunchKernelGGL(kern<float>, dim3(grid_for(total, 256)), dim3(256), 0, ST(stream), __VA_ARGS__);            \
+  } while (0)
+
+extern "C" int pf_resize_bilinear(const void* x, int x_ld, int B, int H, int W, int C, void* y, int y_ld, int OH, int OW,
+                                  const void* add, int add_ld, int in_f32, int out_f32, int dtype, void* stream) {
+  if (!x || !y || C % 8 || x_ld % 8 || y_ld % 8 || (add && add_ld % 8)) return PF_ERR_ARG;
+  const long total = (long)B * OH * OW * (C / 8);
+  LAUNCH_T(resize_bilinear_kernel, total, x, x_ld, B, H, W, C, y, y_ld, OH, OW, add, add_ld, in_f32, out_f32, ac_scale(H, OH), ac_scale(W, OW));
+  return ok();
+}
+
+extern "C" int pf_crop_resize_planar(const float* img, int C, int H, int W, const int* boxes, int P, float* out, int oh, int ow, void* stream) {
+  if (!img || !boxes || !out) return PF_ERR_ARG;
+  const long total = (long)P * C * oh * ow;
+  hipLaunchKernelGGL(crop_resize_planar_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ST(stream), img, C, H, W, boxes, P, out, oh, ow);
+  return ok();
+}
+
+extern "C" int pf_roi_align(const void* feat, int f_ld, int Bf, int H, int W, int C, const float* rois, int K, void* y, int y_ld,
+                            int oh, int ow, float spatial_scale, int in_f32, int out_f32, int dtype, void* stream) {
+  if (!feat || !rois || !y) return PF_ERR_ARG;
+  if (C == 1) {  // planar float depth map
+    if (!in_f32 || !out_f32) return PF_ERR_ARG;
+    hipLaunchKernelGGL(roi_align_scalar_kernel, dim3(grid_for((long)K * oh * ow, 256)), dim3(256), 0, ST(stream), (const float*)feat, Bf, H, W, rois, K, (float*)y, oh, ow, spatial_scale);
+    return ok();
+  }
+  if (C % 8 || f_ld % 8 || y_ld % 8) return PF_ERR_ARG;
+  const long total = (long)K * oh * ow * (C / 8);
+  LAUNCH_T(roi_align_kernel, total, feat, f_ld, Bf, H, W, C, rois, K, y, y_ld, oh, ow, spatial_scale, in_f32, out_f32);
+  return ok();
+}
+
+extern "C" int pf_maxpool2(const void* x, int x_ld, int B, int H, int W, int C, void* y, int y_ld, int dtype, void* stream) {
+  if (!x || !y || C % 8 || x_ld % 8 || y_ld % 8) return PF_ERR_ARG;
+  const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
+  if (dtype == PF_DTYPE_BF16) hipLaunchKernelGGL(maxpool2_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, ST(stream), (const bf16_t*)x, x_ld, B, H, W, C, (bf16_t*)y, y_ld);
+  else hipLaunchKernelGGL(maxpool2_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, ST(stream), (const float*)x, x_ld, B, H, W, C, (float*)y, y_ld);
+  return ok();
+}
+
+extern "C" int pf_copy_channels(const void* x, int x_ld, void* y, int y_ld, long npix, int C, int in_f32, int out_f32, int dtype, void* stream) {
+  if (!x || !y || C % 8 || x_ld % 8 || y_ld % 8) return PF_ERR_ARG;
+  const long total = npix * (C / 8);
+  LAUNCH_T(copy_channels_kernel, total, x, x_ld, y, y_ld, npix, C, in_f32, out_f32);
+  return ok();
+}
+
+extern "C" int pf_pack_fusion_input(const float* cdepth, const float* fdepth, const float* crops, void* y, int B, int h, int w, int dtype, void* stream) {
+  if (!cdepth || !fdepth || !crops || !y) return PF_ERR_ARG;
+  const long total = (long)B * h * w;
+  if (dtype == PF_DTYPE_BF16) hipLaunchKernelGGL(pack_fusion_input_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, ST(stream), cdepth, fdepth, crops, (bf16_t*)y, B, h, w);
+  else hipLaunchKernelGGL(pack_fusion_input_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, ST(stream), cdepth, fdepth, crops, (float*)y, B, h, w);
+  return ok();
+}
+
+extern "C" int pf_nhwc_to_nchw_f32(const void* x, int x_ld, float* y, int B, int H, int W, int C, int in_f32, int dtype, void* stream) {
+  if (!x || !y) return PF_ERR_ARG;
+  const long total = (long)B * C * H * W;
+  LAUNCH_T(nhwc_to_nchw_kernel, total, x, x_ld, y, B, H, W, C, in_f32);
+  return ok();
+}
+
+extern "C" int pf_attractor(const float* A, int a_ld, int n_attr, const float* b_prev, int hp, int wp, float* out, int B, int h, int w,
+                            int n_bins, void* stream) {
+  if (!A || !b_prev || !out || n_bins % 4 || n_attr < 1) return PF_ERR_ARG;
+  const long total = (long)B * h * w * (n_bins / 4);
+  hipLaunchKernelGGL(attractor_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ST(stream), A, a_ld, n_attr, b_prev, hp, wp, out, B, h, w, n_bins, ac_scale(hp, h), ac_scale(wp, w));
+  return ok();
+}
+
+extern "C" int pf_logbinom_depth(const float* pt, int pt_ld, const float* centers, int hc, int wc, float* depth, int B, int h, int w,
+                                 int n_bins, float min_temp, float max_temp, void* stream) {
+  if (!pt || !centers || !depth || n_bins % 4) return PF_ERR_ARG;
+  const long total = (long)B * h * w;
+  hipLaunchKernelGGL(logbinom_depth_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ST(stream), pt, pt_ld, centers, hc, wc, depth, B, h, w, n_bins, min_temp, max_temp, ac_scale(hc, h), ac_scale(wc, w));
+  return ok();
+}
+
+extern "C" int pf_stitch_init(float* pred, float* count, int MH, int MW, const float* depth, const float* mask, const int* yx, int P,
+                              int ph, int pw, void* stream) {
+  if (!pred || !count || !depth || !mask || !yx) return PF_ERR_ARG;
+  const long total = (long)P * ph * pw;
+  hipLaunchKernelGGL(stitch_init_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ST(stream), pred, count, MH, MW, depth, mask, yx, P, ph, pw);
+  return ok();
+}
+extern "C" int pf_stitch_finish_init(float* avg, const float* pred, const float* count, long n, void* stream) {
+  if (!avg || !pred || !count) return PF_ERR_ARG;
+  hipLaunchKernelGGL(div_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ST(stream), avg, pred, count, n);
+  return ok();
+}
+extern "C" int pf_stitch_update(float* avg, float* count, int MH, int MW, const float* depth, int dh, int dw, const float* mask, int y0,
+                                int x0, int ph, int pw, void* stream) {
+  if (!avg || !count || !depth || !mask) return PF_ERR_ARG;
+  const long total = (long)ph * pw;
+  hipLaunchKernelGGL(stitch_update_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ST(stream), avg, count, MH, MW, depth, dh, dw, mask, y0, x0, ph, pw, (float)dh / (float)ph, (float)dw / (float)pw);
+  return ok();
+}
+extern "C" int pf_resize_nearest_f32(const float* x, int H, int W, float* y, int OH, int OW, void* stream) {
+  if (!x || !y) return PF_ERR_ARG;
+  const long total = (long)OH * OW;
+  hipLaunchKernelGGL(resize_nearest_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ST(stream), x, H, W, y, OH, OW, (float)H / (float)OH, (float)W / (float)OW);
+  return ok();
+}
+extern "C" int pf_resize_bilinear_f32(const float* x, int H, int W, float* y, int OH, int OW, void* stream) {
+  if (!x || !y) return PF_ERR_ARG;
+  const long total = (long)OH * OW;
+  hipLaunchKernelGGL(resize_bilinear_f32_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ST(stream), x, H, W, y, OH, OW, ac_scale(H, OH), ac_scale(W, OW));
+  return ok();
+}

@@ -1,0 +1,366 @@
+// ViT (DINOv2) encoder kernels other than the linear layers (those run on igemm.hip):
+// patch im2col + ImageNet normalisation, token assembly, LayerNorm, qkv head split and the fused
+// softmax attention on the matrix cores.
+#include "pf_common.h"
+#include "../../include/pf_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// im2col for the 14x14/14 patch embedding, fused with (x - mean) / std.
+// out[(b,ty,tx)][(ky*14+kx)*3 + c], columns 588..ld-1 zero.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void patch_im2col_kernel(const float* __restrict__ img, int B, int H, int W, T* __restrict__ out, int ld) {
+  const int th = H / 14, tw = W / 14;
+  const long total = (long)B * th * tw * ld;
+  const float mean[3] = {0.485f, 0.456f, 0.406f};
+  const float stdv[3] = {0.229f, 0.224f, 0.225f};
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % ld);
+    const long row = i / ld;
+    float v = 0.f;
+    if (k < 588) {
+      const int c = k % 3, kk = k / 3, kx = kk % 14, ky = kk / 14;
+      const int tx = (int)(row % tw), ty = (int)((row / tw) % th), b = (int)(row / ((long)tw * th));
+      const float px = img[(((long)b * 3 + c) * H + (ty * 14 + ky)) * W + (tx * 14 + kx)];
+      v = (px - mean[c]) / stdv[c];
+    }
+    Elem<T>::st(out + i, v);
+  }
+}
+
+// tokens[b,0,:] = cls + pos[0]; tokens[b,1+t,:] = emb[b*(S-1)+t,:] + pos[1+t]
+template <typename T>
+__global__ void assemble_tokens_kernel(const T* __restrict__ emb, T* __restrict__ tok, const float* __restrict__ cls,
+                                       const float* __restrict__ pos, int B, int S, int D) {
+  const long total = (long)B * S * D;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    const int s = (int)((i / D) % S);
+    const int b = (int)(i / ((long)D * S));
+    float v = (s == 0) ? cls[d] : Elem<T>::ld(emb + ((long)b * (S - 1) + (s - 1)) * D + d);
+    Elem<T>::st(tok + i, v + pos[(long)s * D + d]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, D <= 2048, two-pass statistics in f32.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, int x_ld, T* __restrict__ y, int y_ld,
+                                                        const float* __restrict__ g, const float* __restrict__ bta,
+                                                        float eps, int batches, int in_rpb, int in_off, int out_rpb, int D) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long)batches * out_rpb) return;
+  const int b = (int)(row / out_rpb), t = (int)(row % out_rpb);
+  const T* xr = x + ((long)b * in_rpb + in_off + t) * x_ld;
+  T* yr = y + row * y_ld;
+  const int nv = D >> 3;
+  float v[4][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int vi = lane + 64 * i;
+    if (vi < nv) {
+      load8(xr + vi * 8, v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[i][e];
+    }
+  }
+  const float mean = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int vi = lane + 64 * i;
+    if (vi < nv) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int vi = lane + 64 * i;
+    if (vi < nv) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * g[vi * 8 + e] + bta[vi * 8 + e];
+      store8(yr + vi * 8, o);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// qkv split: qkv [B*S][3][Hh][64] -> Q*scale [B,Hh,S,64], K [B,Hh,S,64], V^T [B,Hh,64,Sp]
+// grid (ceil(S/64), B*Hh), 256 threads.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void qkv_split_kernel(const T* __restrict__ qkv, int B, int S, int Hh, T* __restrict__ q,
+                                                        T* __restrict__ k, T* __restrict__ vt, int Sp, float scale) {
+  __shared__ float vs[64][65];
+  const int D = Hh * 64;
+  const int bh = blockIdx.y, b = bh / Hh, h = bh % Hh;
+  const int s0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+  // 64 tokens x 8 vectors-of-8 per matrix
+  for (int i = tid; i < 64 * 8; i += 256) {
+    const int t = i >> 3, vj = i & 7;
+    const int s = s0 + t;
+    float a[8];
+    if (s < S) {
+      const T* src = qkv + ((long)b * S + s) * 3 * D + h * 64 + vj * 8;
+      load8(src, a);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] *= scale;
+      store8(q + (((long)bh * S + s) * 64) + vj * 8, a);
+      load8(src + D, a);
+      store8(k + (((long)bh * S + s) * 64) + vj * 8, a);
+      load8(src + 2 * D, a);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) vs[t][vj * 8 + e] = a[e];
+  }
+  __syncthreads();
+  {
+    const int d = tid >> 2, tc = (tid & 3) * 16;
+    T* dst = vt + ((long)bh * 64 + d) * Sp + s0 + tc;
+    float a[8];
+#pragma unroll
+    for (int hlf = 0; hlf < 2; ++hlf) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] = vs[tc + hlf * 8 + e][d];
+      store8(dst + hlf * 8, a);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused attention, head_dim 64.  Block = 4 waves, each wave 16 queries; KV tiles of 64 keys staged
+// in LDS (K as [key][d], V^T as [d][key], 16-byte slots XOR-swizzled).  Scores are computed
+// TRANSPOSED (S^T = K Q^T) so that a lane's 16 score registers all belong to ONE query: the row
+// max / sum are in-lane plus two cross-lane-group shuffles, and exp(S^T) is directly the MFMA "B"
+// operand of O^T = V^T P^T.
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct AttnCfg;
+template <> struct AttnCfg<bf16_t> { static constexpr int ROWB = 128, SPR = 8; };
+template <> struct AttnCfg<float> { static constexpr int ROWB = 256, SPR = 16; };
+
+template <typename T> __device__ __forceinline__ int attn_swz(int row, int slot) {
+  if constexpr (sizeof(T) == 2) return slot ^ ((row >> 1) & 7);
+  else return slot ^ (row & 15);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void vit_attention_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                            const T* __restrict__ vt, T* __restrict__ out, int B, int S,
+                                                            int Sp, int Hh) {
+  constexpr int ROWB = AttnCfg<T>::ROWB, SPR = AttnCfg<T>::SPR;
+  constexpr int VEC = Elem<T>::VEC;
+  __shared__ __attribute__((aligned(16))) char lds[2 * 64 * ROWB];
+  char* Ks = lds;
+  char* Vs = lds + 64 * ROWB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.y, b = bh / Hh, h = bh % Hh;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int D = Hh * 64;
+  const T* qb = q + (long)bh * S * 64;
+  const T* kb = k + (long)bh * S * 64;
+  const T* vb = vt + (long)bh * 64 * Sp;
+
+  // Q fragments for query q0 + r (clamped; out-of-range queries are never stored)
+  const int qi = min(q0 + r, S - 1);
+  uint4 qf[sizeof(T) == 2 ? 2 : 4];
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const uint4*>(qb + (long)qi * 64 + ks * 32 + g * 8);
+  } else {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) qf[s4] = *reinterpret_cast<const uint4*>(qb + (long)qi * 64 + s4 * 16 + g * 4);
+  }
+
+  f32x4 o[4];
+#pragma unroll
+  for (int fd = 0; fd < 4; ++fd) o[fd] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int ntiles = (S + 63) / 64;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    __syncthreads();
+    // ---- stage K tile [64 keys][64 d] and V^T tile [64 d][64 keys] ----
+    {
+      constexpr int RPP = 256 / SPR;  // rows per pass
+      const int j = tid % SPR, rr0 = tid / SPR;
+#pragma unroll
+      for (int i = 0; i < 64 / RPP; ++i) {
+        const int row = rr0 + RPP * i;
+        const int key = kt * 64 + row;
+        uint4 kv = make_uint4(0, 0, 0, 0);
+        if (key < S) kv = *reinterpret_cast<const uint4*>(kb + (long)key * 64 + j * VEC);
+        *reinterpret_cast<uint4*>(Ks + row * ROWB + (attn_swz<T>(row, j) << 4)) = kv;
+        const uint4 vv = *reinterpret_cast<const uint4*>(vb + (long)row * Sp + kt * 64 + j * VEC);
+        *reinterpret_cast<uint4*>(Vs + row * ROWB + (attn_swz<T>(row, j) << 4)) = vv;
+      }
+    }
+    __syncthreads();
+    // ---- S^T = K Q^T ----
+    f32x4 sc[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      sc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int row = f * 16 + r;
+      if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const uint4 a = *reinterpret_cast<const uint4*>(Ks + row * ROWB + (attn_swz<T>(row, ks * 4 + g) << 4));
+          sc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, qf[ks]),
+                                                         sc[f], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const uint4 a = *reinterpret_cast<const uint4*>(Ks + row * ROWB + (attn_swz<T>(row, s4 * 4 + g) << 4));
+          sc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(qf[s4].x), sc[f], 0, 0, 0);
+          sc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(qf[s4].y), sc[f], 0, 0, 0);
+          sc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(qf[s4].z), sc[f], 0, 0, 0);
+          sc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(qf[s4].w), sc[f], 0, 0, 0);
+        }
+      }
+    }
+    // ---- online softmax for query (lane & 15); this lane holds keys kt*64 + f*16 + g*4 + e ----
+    float mx = -INFINITY;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int key = kt * 64 + f * 16 + g * 4 + e;
+        if (key >= S) sc[f][e] = -INFINITY;
+        mx = fmaxf(mx, sc[f][e]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = expf(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pe = expf(sc[f][e] - m_new);
+        sc[f][e] = pe;
+        psum += pe;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int fd = 0; fd < 4; ++fd)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[fd][e] *= alpha;
+    // ---- O^T += V^T P^T ----
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        uint4 pb;
+        pb.x = (uint32_t)f2bf(sc[2 * jj][0]) | ((uint32_t)f2bf(sc[2 * jj][1]) << 16);
+        pb.y = (uint32_t)f2bf(sc[2 * jj][2]) | ((uint32_t)f2bf(sc[2 * jj][3]) << 16);
+        pb.z = (uint32_t)f2bf(sc[2 * jj + 1][0]) | ((uint32_t)f2bf(sc[2 * jj + 1][1]) << 16);
+        pb.w = (uint32_t)f2bf(sc[2 * jj + 1][2]) | ((uint32_t)f2bf(sc[2 * jj + 1][3]) << 16);
+#pragma unroll
+        for (int fd = 0; fd < 4; ++fd) {
+          const int row = fd * 16 + r;
+          // keys (2jj)*16 + g*4 .. +3 -> byte (2jj)*32 + g*8 ; keys (2jj+1)*16 + g*4 .. -> byte (2jj+1)*32 + g*8
+          const int slot0 = (2 * jj) * 2 + (g >> 1), slot1 = (2 * jj + 1) * 2 + (g >> 1);
+          const uint2 lo = *reinterpret_cast<const uint2*>(Vs + row * ROWB + (attn_swz<T>(row, slot0) << 4) + (g & 1) * 8);
+          const uint2 hi = *reinterpret_cast<const uint2*>(Vs + row * ROWB + (attn_swz<T>(row, slot1) << 4) + (g & 1) * 8);
+          const uint4 a = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          o[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, pb), o[fd],
+                                                         0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+#pragma unroll
+        for (int fd = 0; fd < 4; ++fd) {
+          const int row = fd * 16 + r;
+          const uint4 a = *reinterpret_cast<const uint4*>(Vs + row * ROWB + (attn_swz<T>(row, f * 4 + g) << 4));
+          o[fd] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), sc[f][0], o[fd], 0, 0, 0);
+          o[fd] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), sc[f][1], o[fd], 0, 0, 0);
+          o[fd] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), sc[f][2], o[fd], 0, 0, 0);
+          o[fd] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), sc[f][3], o[fd], 0, 0, 0);
+        }
+      }
+    }
+  }
+  float l = l_run;
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l;
+  const int qo = q0 + r;
+  if (qo < S) {
+    T* dst = out + ((long)b * S + qo) * D + h * 64 + g * 4;
+#pragma unroll
+    for (int fd = 0; fd < 4; ++fd) store4(dst + fd * 16, o[fd][0] * inv, o[fd][1] * inv, o[fd][2] * inv, o[fd][3] * inv);
+  }
+}
+
+inline int grid_for(long n, int block) {
+  long g = (n + block - 1) / block;
+  return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+inline int ok() { return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_LAUNCH; }
+
+}  // namespace
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int pf_patch_im2col(const float* img, int B, int H, int W, void* out, int ld, int dtype, void* stream) {
+  if (!img || !out || H % 14 || W % 14 || ld < 588) return PF_ERR_ARG;
+  const long total = (long)B * (H / 14) * (W / 14) * ld;
+  if (dtype == PF_DTYPE_BF16) hipLaunchKernelGGL(patch_im2col_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, ST(stream), img, B, H, W, (bf16_t*)out, ld);
+  else hipLaunchKernelGGL(patch_im2col_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, ST(stream), img, B, H, W, (float*)out, ld);
+  return ok();
+}
+
+extern "C" int pf_assemble_tokens(const void* emb, void* tokens, const float* cls, const float* pos, int B, int S, int D,
+                                  int dtype, void* stream) {
+  if (!emb || !tokens || !cls || !pos) return PF_ERR_ARG;
+  const long total = (long)B * S * D;
+  if (dtype == PF_DTYPE_BF16) hipLaunchKernelGGL(assemble_tokens_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, ST(stream), (const bf16_t*)emb, (bf16_t*)tokens, cls, pos, B, S, D);
+  else hipLaunchKernelGGL(assemble_tokens_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, ST(stream), (const float*)emb, (float*)tokens, cls, pos, B, S, D);
+  return ok();
+}
+
+extern "C" int pf_layernorm(const void* x, int x_ld, void* y, int y_ld, const float* g, const float* b, float eps,
+                            int batches, int in_rows_per_batch, int in_row_offset, int out_rows_per_batch, int D,
+                            int dtype, void* stream) {
+  if (!x || !y || !g || !b || D % 8 || D > 2048 || x_ld % 8 || y_ld % 8) return PF_ERR_ARG;
+  const long rows = (long)batches * out_rows_per_batch;
+  const int grid = (int)((rows + 3) / 4);
+  if (dtype == PF_DTYPE_BF16) hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3(grid), dim3(256), 0, ST(stream), (const bf16_t*)x, x_ld, (bf16_t*)y, y_ld, g, b, eps, batches, in_rows_per_batch, in_row_offset, out_rows_per_batch, D);
+  else hipLaunchKernelGGL(layernorm_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (const float*)x, x_ld, (float*)y, y_ld, g, b, eps, batches, in_rows_per_batch, in_row_offset, out_rows_per_batch, D);
+  return ok();
+}
+
+extern "C" int pf_qkv_split(const void* qkv, int B, int S, int Hh, void* q, void* k, void* vt, int Sp, float scale,
+                            int dtype, void* stream) {
+  if (!qkv || !q || !k || !vt || Sp % 64 || Sp < S) return PF_ERR_ARG;
+  dim3 grid((S + 63) / 64, B * Hh);
+  if (dtype == PF_DTYPE_BF16) hipLaunchKernelGGL(qkv_split_kernel<bf16_t>, grid, dim3(256), 0, ST(stream), (const bf16_t*)qkv, B, S, Hh, (bf16_t*)q, (bf16_t*)k, (bf16_t*)vt, Sp, scale);
+  else hipLaunchKernelGGL(qkv_split_kernel<float>, grid, dim3(256), 0, ST(stream), (const float*)qkv, B, S, Hh, (float*)q, (float*)k, (float*)vt, Sp, scale);
+  return ok();
+}
+
+extern "C" int pf_vit_attention(const void* q, const void* k, const void* vt, void* out, int B, int S, int Sp, int Hh,
+                                int dtype, void* stream) {
+  if (!q || !k || !vt || !out || Sp % 64 || Sp < S) return PF_ERR_ARG;
+  dim3 grid((S + 63) / 64, B * Hh);
+  if (dtype == PF_DTYPE_BF16) hipLaunchKernelGGL(vit_attention_kernel<bf16_t>, grid, dim3(256), 0, ST(stream), (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, B, S, Sp, Hh);
+  else hipLaunchKernelGGL(vit_attention_kernel<float>, grid, dim3(256), 0, ST(stream), (const float*)q, (const float*)k, (const float*)vt, (float*)out, B, S, Sp, Hh);
+  return ok();
+}

@@ -1,0 +1,290 @@
+"""Typed Python wrappers over the C ABI (include/pf_hip.h).
+
+Every function takes torch tensors that live on the GPU, extracts raw device pointers / strides and
+launches the hand-written HIP kernel on torch's *current* stream.  PyTorch is used for memory and
+streams only.  There is no CPU path here: CPU tensors are rejected and a missing shared library
+makes this module fail to import (see _lib.load).
+
+Tensor conventions: activations are NHWC views ``[B,H,W,C]`` (or token matrices ``[M,C]``) with
+unit channel stride; the pixel stride (``ld``) may exceed C when the tensor is a channel slice of a
+concat buffer.  dtype float32 = exact mode, bfloat16 = fast mode; a few head tensors are always f32.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvParams, check
+from .packing import PackedConv
+
+_L = _lib.load()
+
+ACT = {"none": 0, None: 0, "relu": 1, "gelu": 2, "softplus": 3}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.PfError("patchfusion_amd.hip_ops: tensor is not on the GPU (there is no CPU path)")
+    return C.c_void_p(t.data_ptr())
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return 0
+    if t.dtype == torch.bfloat16:
+        return 1
+    raise _lib.PfError(f"unsupported dtype {t.dtype}")
+
+
+def _as4(t):
+    if t.dim() == 2:
+        return t.unsqueeze(0).unsqueeze(0)
+    if t.dim() == 3:
+        return t.unsqueeze(0)
+    return t
+
+
+def _ld(t):
+    """pixel stride of a dense-in-(B,H,W) NHWC view"""
+    t = _as4(t)
+    B, H, W, Cc = t.shape
+    assert t.stride(3) == 1, "channel stride must be 1"
+    ld = t.stride(2) if W > 1 else (t.stride(1) if H > 1 else max(Cc, t.stride(2)))
+    if W > 1 and H > 1:
+        assert t.stride(1) == W * ld, "rows must be dense"
+    if B > 1:
+        assert t.stride(0) == H * W * ld, "batches must be dense"
+    return ld
+
+
+class HipOps:
+    name = "hip"
+
+    # ---------------- allocation ----------------
+    @staticmethod
+    def empty(shape, dtype, device):
+        return torch.empty(shape, dtype=dtype, device=device)
+
+    @staticmethod
+    def zeros(shape, dtype, device):
+        return torch.zeros(shape, dtype=dtype, device=device)
+
+    # ---------------- conv / linear ----------------
+    @staticmethod
+    def conv(x, pw: PackedConv, y, stride=1, pad=0, act=None, relu_in=False, res=None, res2=None, _timed=None):
+        x4, y4 = _as4(x), _as4(y)
+        B, H, W, _ = x4.shape
+        OH = (H + 2 * pad - pw.KH) // stride + 1
+        OW = (W + 2 * pad - pw.KW) // stride + 1
+        s = pw.shuffle
+        assert y4.shape[0] == B and y4.shape[1] == OH * s and y4.shape[2] == OW * s, (x4.shape, y4.shape, OH, OW, s)
+        assert x4.shape[3] >= pw.cin and y4.shape[3] >= pw.cout // (s * s), (x4.shape, y4.shape, pw.cin, pw.cout)
+        p = ConvParams()
+        p.x, p.x_ld, p.B, p.H, p.W, p.Cin = x4.data_ptr(), _ld(x4), B, H, W, pw.cin
+        p.w, p.w_rows, p.Kpad = pw.w.data_ptr(), pw.w.shape[0], pw.w.shape[1]
+        p.bias = pw.bias.data_ptr() if pw.bias is not None else None
+        p.scale = pw.scale.data_ptr() if pw.scale is not None else None
+        p.res = res.data_ptr() if res is not None else None
+        p.res_ld = _ld(res) if res is not None else 0
+        p.res2 = res2.data_ptr() if res2 is not None else None
+        p.res2_ld = _ld(res2) if res2 is not None else 0
+        p.y, p.y_ld, p.OH, p.OW, p.Cout = y4.data_ptr(), _ld(y4), OH, OW, pw.cout
+        p.KH, p.KW, p.stride, p.pad = pw.KH, pw.KW, stride, pad
+        p.act, p.relu_in = ACT[act], int(bool(relu_in))
+        p.dtype = _dt(x4)
+        assert pw.w.dtype == x4.dtype, "weights must be packed in the activation dtype"
+        p.out_f32 = int(y4.dtype == torch.float32 and x4.dtype != torch.float32)
+        p.shuffle = s
+        for t in (x4, y4, pw.w, res, res2):
+            _p(t)
+        if _timed is not None:
+            ms = C.c_float(0)
+            check(_L.pf_conv_timed(C.byref(p), int(_timed), C.byref(ms), _stream()), "pf_conv_timed")
+            return ms.value
+        check(_L.pf_conv(C.byref(p), _stream()), "pf_conv")
+        return y
+
+    # ---------------- ViT ----------------
+    @staticmethod
+    def patch_im2col(img, out):
+        B, _, H, W = img.shape
+        assert img.dtype == torch.float32 and img.is_contiguous()
+        check(_L.pf_patch_im2col(_p(img), B, H, W, _p(out), out.stride(0), _dt(out), _stream()), "pf_patch_im2col")
+
+    @staticmethod
+    def assemble_tokens(emb, tokens, cls, pos):
+        B, S, D = tokens.shape
+        assert emb.is_contiguous() and tokens.is_contiguous()
+        check(_L.pf_assemble_tokens(_p(emb), _p(tokens), _p(cls), _p(pos), B, S, D, _dt(tokens), _stream()), "pf_assemble_tokens")
+
+    @staticmethod
+    def layernorm(x, y, g, b, eps, batches=1, in_rows_per_batch=None, in_row_offset=0, out_rows_per_batch=None):
+        D = x.shape[-1]
+        rows = x.numel() // D
+        if in_rows_per_batch is None:
+            in_rows_per_batch = out_rows_per_batch = rows
+            batches = 1
+        check(_L.pf_layernorm(_p(x), x.stride(-2), _p(y), y.stride(-2), _p(g), _p(b), float(eps), batches, in_rows_per_batch,
+                              in_row_offset, out_rows_per_batch, D, _dt(x), _stream()), "pf_layernorm")
+
+    @staticmethod
+    def vit_attention(qkv, out, B, S, heads):
+        """qkv [B*S, 3*D] -> out [B*S, D]; head_dim must be 64."""
+        D = qkv.shape[1] // 3
+        assert D == heads * 64 and qkv.is_contiguous() and out.is_contiguous()
+        Sp = (S + 63) // 64 * 64
+        q = torch.empty((B, heads, S, 64), dtype=qkv.dtype, device=qkv.device)
+        k = torch.empty_like(q)
+        vt = torch.empty((B, heads, 64, Sp), dtype=qkv.dtype, device=qkv.device)
+        check(_L.pf_qkv_split(_p(qkv), B, S, heads, _p(q), _p(k), _p(vt), Sp, 0.125, _dt(qkv), _stream()), "pf_qkv_split")
+        check(_L.pf_vit_attention(_p(q), _p(k), _p(vt), _p(out), B, S, Sp, heads, _dt(qkv), _stream()), "pf_vit_attention")
+
+    # ---------------- Swin / G2L ----------------
+    @staticmethod
+    def swin_ln_partition(x, xw, g, b, eps, shift):
+        B, H, W, Cc = x.shape
+        assert xw.is_contiguous()
+        check(_L.pf_swin_ln_partition(_p(x), _ld(x), _p(xw), _p(g), _p(b), float(eps), B, H, W, Cc, shift, _dt(x), _stream()),
+              "pf_swin_ln_partition")
+
+    @staticmethod
+    def swin_window_attention(qkv, out, bias_table, B, Hp, Wp, Cc, heads, shift):
+        assert qkv.is_contiguous() and out.is_contiguous() and bias_table.is_contiguous()
+        check(_L.pf_swin_window_attention(_p(qkv), _p(out), _p(bias_table), B, Hp, Wp, Cc, heads, shift, _dt(qkv), _stream()),
+              "pf_swin_window_attention")
+
+    @staticmethod
+    def swin_unpartition_add(proj, shortcut, y, shift):
+        B, H, W, Cc = shortcut.shape
+        check(_L.pf_swin_unpartition_add(_p(proj), _p(shortcut), _ld(shortcut), _p(y), _ld(y), B, H, W, Cc, shift, _dt(y), _stream()),
+              "pf_swin_unpartition_add")
+
+    @staticmethod
+    def add_rowwise(x, pos):
+        """x [B,T,C] += pos [T,C] (float32)"""
+        B, T, Cc = x.shape
+        check(_L.pf_add_rowwise(_p(x), x.stride(1), _p(pos), B, T, Cc, _dt(x), _stream()), "pf_add_rowwise")
+
+    # ---------------- image ops ----------------
+    @staticmethod
+    def resize(x, y, add=None, dtype=None):
+        x4, y4 = _as4(x), _as4(y)
+        B, H, W, Cc = x4.shape
+        _, OH, OW, _ = y4.shape
+        cd = dtype if dtype is not None else (x4.dtype if x4.dtype != torch.float32 else y4.dtype)
+        code = 1 if cd == torch.bfloat16 else 0
+        in_f32 = int(x4.dtype == torch.float32)
+        out_f32 = int(y4.dtype == torch.float32)
+        if add is not None:
+            assert add.dtype == y4.dtype
+        check(_L.pf_resize_bilinear(_p(x4), _ld(x4), B, H, W, Cc, _p(y4), _ld(y4), OH, OW, _p(add), _ld(add) if add is not None else 0,
+                                    in_f32, out_f32, code, _stream()), "pf_resize_bilinear")
+
+    @staticmethod
+    def crop_resize(img, boxes, out):
+        """img [3,H,W] f32; boxes int32 [P,4] (x0,y0,x1,y1) on device; out [P,3,oh,ow] f32"""
+        Cc, H, W = img.shape
+        P, _, oh, ow = out.shape
+        assert img.is_contiguous() and out.is_contiguous() and boxes.dtype == torch.int32
+        check(_L.pf_crop_resize_planar(_p(img), Cc, H, W, _p(boxes), P, _p(out), oh, ow, _stream()), "pf_crop_resize_planar")
+
+    @staticmethod
+    def roi_align_depth(feat, rois, y, spatial_scale):
+        """single-channel planar float map: feat [Bf,1,H,W] f32 -> y [K,1,oh,ow] f32"""
+        Bf, _, H, W = feat.shape
+        K, _, oh, ow = y.shape
+        assert feat.is_contiguous() and y.is_contiguous() and feat.dtype == y.dtype == torch.float32
+        check(_L.pf_roi_align(_p(feat), 1, Bf, H, W, 1, _p(rois), K, _p(y), 1, oh, ow, float(spatial_scale), 1, 1, 0, _stream()),
+              "pf_roi_align")
+
+    @staticmethod
+    def roi_align(feat, rois, y, spatial_scale, dtype=None):
+        """feat [Bf,H,W,C] NHWC; rois f32 [K,5]; y [K,oh,ow,C]"""
+        Bf, H, W, Cc = feat.shape
+        K, oh, ow, _ = y.shape
+        code = 1 if (dtype or feat.dtype) == torch.bfloat16 else 0
+        check(_L.pf_roi_align(_p(feat), _ld(feat), Bf, H, W, Cc, _p(rois), K, _p(y), _ld(y), oh, ow, float(spatial_scale),
+                              int(feat.dtype == torch.float32), int(y.dtype == torch.float32), code, _stream()), "pf_roi_align")
+
+    @staticmethod
+    def maxpool2(x, y):
+        B, H, W, Cc = x.shape
+        check(_L.pf_maxpool2(_p(x), _ld(x), B, H, W, Cc, _p(y), _ld(y), _dt(x), _stream()), "pf_maxpool2")
+
+    @staticmethod
+    def copy_channels(x, y):
+        x4, y4 = _as4(x), _as4(y)
+        B, H, W, Cc = x4.shape
+        code = 1 if torch.bfloat16 in (x4.dtype, y4.dtype) else 0
+        check(_L.pf_copy_channels(_p(x4), _ld(x4), _p(y4), _ld(y4), B * H * W, Cc, int(x4.dtype == torch.float32),
+                                  int(y4.dtype == torch.float32), code, _stream()), "pf_copy_channels")
+
+    @staticmethod
+    def pack_fusion_input(cdepth, fdepth, crops, y):
+        B, h, w, c8 = y.shape
+        assert c8 == 8 and y.is_contiguous() and cdepth.is_contiguous() and fdepth.is_contiguous() and crops.is_contiguous()
+        check(_L.pf_pack_fusion_input(_p(cdepth), _p(fdepth), _p(crops), _p(y), B, h, w, _dt(y), _stream()), "pf_pack_fusion_input")
+
+    @staticmethod
+    def nhwc_to_nchw(x, Cc=None):
+        B, H, W, Ct = x.shape
+        Cc = Cc or Ct
+        y = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device)
+        code = 1 if x.dtype == torch.bfloat16 else 0
+        check(_L.pf_nhwc_to_nchw_f32(_p(x), _ld(x), _p(y), B, H, W, Cc, int(x.dtype == torch.float32), code, _stream()), "pf_nhwc_to_nchw_f32")
+        return y
+
+    # ---------------- metric-bins head ----------------
+    @staticmethod
+    def attractor(A, n_attr, b_prev, out):
+        """A [B,h,w,>=n_attr] f32 ; b_prev [B,hp,wp,n_bins] f32 ; out [B,h,w,n_bins] f32"""
+        B, h, w, nb = out.shape
+        _, hp, wp, _ = b_prev.shape
+        assert A.dtype == b_prev.dtype == out.dtype == torch.float32 and b_prev.is_contiguous() and out.is_contiguous()
+        check(_L.pf_attractor(_p(A), _ld(A), n_attr, _p(b_prev), hp, wp, _p(out), B, h, w, nb, _stream()), "pf_attractor")
+
+    @staticmethod
+    def logbinom_depth(pt, centers, depth, min_temp, max_temp):
+        """pt [B,h,w,>=4] f32 (softplus applied); centers [B,hc,wc,n_bins] f32; depth [B,h,w] f32"""
+        B, h, w = depth.shape
+        _, hc, wc, nb = centers.shape
+        assert pt.dtype == centers.dtype == depth.dtype == torch.float32 and centers.is_contiguous() and depth.is_contiguous()
+        check(_L.pf_logbinom_depth(_p(pt), _ld(pt), _p(centers), hc, wc, _p(depth), B, h, w, nb, float(min_temp), float(max_temp), _stream()),
+              "pf_logbinom_depth")
+
+    # ---------------- stitching ----------------
+    @staticmethod
+    def stitch_init(pred, count, depth, mask, yx):
+        MH, MW = pred.shape
+        P, ph, pw = depth.shape
+        assert depth.is_contiguous() and mask.is_contiguous() and yx.dtype == torch.int32
+        check(_L.pf_stitch_init(_p(pred), _p(count), MH, MW, _p(depth), _p(mask), _p(yx), P, ph, pw, _stream()), "pf_stitch_init")
+
+    @staticmethod
+    def stitch_finish_init(avg, pred, count):
+        check(_L.pf_stitch_finish_init(_p(avg), _p(pred), _p(count), avg.numel(), _stream()), "pf_stitch_finish_init")
+
+    @staticmethod
+    def stitch_update(avg, count, depth, mask, y0, x0):
+        MH, MW = avg.shape
+        dh, dw = depth.shape
+        ph, pw = mask.shape
+        assert depth.is_contiguous() and mask.is_contiguous()
+        check(_L.pf_stitch_update(_p(avg), _p(count), MH, MW, _p(depth), dh, dw, _p(mask), int(y0), int(x0), ph, pw, _stream()), "pf_stitch_update")
+
+    @staticmethod
+    def resize_nearest_f32(x, y):
+        check(_L.pf_resize_nearest_f32(_p(x), x.shape[0], x.shape[1], _p(y), y.shape[0], y.shape[1], _stream()), "pf_resize_nearest_f32")
+
+    @staticmethod
+    def resize_bilinear_f32(x, y):
+        check(_L.pf_resize_bilinear_f32(_p(x), x.shape[0], x.shape[1], _p(y), y.shape[0], y.shape[1], _stream()), "pf_resize_bilinear_f32")
+
+
+ops = HipOps()

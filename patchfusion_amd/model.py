@@ -1,0 +1,297 @@
+"""Drop-in boundary: ``PatchFusion`` with the reference's constructor, ``forward`` signature,
+checkpoint keys and helper attributes (estimator/models/patchfusion.py:57-453,
+estimator/models/baseline_pretrain.py:91-331), executing on the MI355X HIP engine.
+
+What is mirrored:
+  * ``PatchFusion(config)`` with the mmengine ``model.config`` mapping (ConfigDict or plain dict)
+  * ``state_dict()`` keys/shapes identical to the reference (1030 tensors for vits) so reference
+    ``.pth`` / HF checkpoints load by key; ``load_dict`` (strict=False) and ``get_save_dict``
+  * ``forward(mode, image_lr, image_hr, depth_gt=None, crops_image_hr=None, crop_depths=None, bboxs=None,
+    tile_cfg=None, cai_mode='m1', process_num=4)`` -> ``(depth [1,1,H',W'], {'rgb','depth_pred','depth_gt'})``
+  * ``tile_cfg``, ``resizer``, ``patch_process_shape``, ``coarse_forward``, ``fine_forward``, ``infer_forward``
+  * errors: AssertionError for divisibility / batch-1, NotImplementedError for unknown branch types,
+    ValueError for bin_centers_type -- same exception types as the reference.
+Out of scope (north star is inference): ``mode='train'`` raises NotImplementedError.
+
+Multi-GPU: when torch.distributed is initialised and ``shard_patches=True`` the tiles of ONE image
+are sharded over ranks (contiguous chunks) and the per-patch depths are all-gathered over RCCL.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import tiling
+from .config import AttrDict
+from .spec import patchfusion_spec
+
+try:  # HF mixin keeps `from_pretrained` / `save_pretrained` available like the reference class
+    from huggingface_hub import PyTorchModelHubMixin
+except Exception:  # pragma: no cover
+    class PyTorchModelHubMixin:  # type: ignore
+        pass
+
+_DTYPES = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16,
+           torch.float32: torch.float32, torch.bfloat16: torch.bfloat16}
+
+
+class Resizer:
+    """depth_anything/transform.py Resize(width, height, keep_aspect_ratio=False,
+    ensure_multiple_of=m, resize_method='minimal'): bilinear align_corners=True to the multiple of m
+    nearest to the target.  CUDA tensors go through the HIP crop-resize kernel; CPU tensors (dataset-side
+    preprocessing, tools/test_single_forward.py:20) use torch's interpolate."""
+
+    def __init__(self, width, height, multiple_of=14):
+        self.width, self.height, self.m = width, height, multiple_of
+
+    def get_size(self, width, height):
+        sh, sw = self.height / height, self.width / width
+        nh = int(round(sh * height / self.m) * self.m)
+        nw = int(round(sw * width / self.m) * self.m)
+        return nw, nh
+
+    def __call__(self, x):
+        nw, nh = self.get_size(x.shape[-1], x.shape[-2])
+        if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] == 1:
+            from .hip_ops import ops
+            H, W = x.shape[-2:]
+            out = torch.empty((1, x.shape[1], nh, nw), dtype=torch.float32, device=x.device)
+            box = torch.tensor([[0, 0, W, H]], dtype=torch.int32, device=x.device)
+            ops.crop_resize(x[0].contiguous(), box, out)
+            return out
+        return F.interpolate(x, (nh, nw), mode='bilinear', align_corners=True)
+
+
+def _build_param_tree(root, spec):
+    """Register every checkpoint tensor under its dotted name so state_dict()/load_state_dict()/.to()
+    behave exactly like the reference's module tree (containers only, no forward code)."""
+    for name, e in spec.items():
+        parts = name.split('.')
+        mod = root
+        for p in parts[:-1]:
+            if p not in mod._modules:
+                mod.add_module(p, nn.Module())
+            mod = mod._modules[p]
+        leaf = parts[-1]
+        if e.dtype.is_floating_point and e.kind not in ("bn_mean", "bn_var", "k_minus_1"):
+            mod.register_parameter(leaf, nn.Parameter(torch.zeros(e.shape, dtype=e.dtype), requires_grad=False))
+        else:
+            mod.register_buffer(leaf, torch.zeros(e.shape, dtype=e.dtype))
+
+
+class PatchFusion(nn.Module, PyTorchModelHubMixin):
+    def __init__(self, config, compute_dtype=None, ops=None, shard_patches=True):
+        nn.Module.__init__(self)
+        if hasattr(config, "to_dict") and not isinstance(config, AttrDict):
+            config = config.to_dict()
+        config = AttrDict(dict(config))
+        self.config = config
+        self.min_depth, self.max_depth = config.min_depth, config.max_depth
+        self.patch_process_shape = tuple(config.patch_process_shape)
+        self.tile_cfg = self.prepare_tile_cfg(config.image_raw_shape, config.patch_split_num)
+        self.coarse_branch_cfg = config.coarse_branch
+        for br in (config.coarse_branch, config.fine_branch):
+            if br.type == 'DA-ZoeDepth':
+                if br.midas_model_type not in ('vits', 'vitb', 'vitl'):
+                    raise NotImplementedError(br.midas_model_type)
+            elif br.type == 'ZoeDepth':
+                # BEiT/MiDaS encoder lives in an un-vendored torch.hub repo (midas.py:340): parity unpinned
+                raise NotImplementedError("ZoeDepth (MiDaS BEiT) branch is not built yet; see DESIGN.md out-of-scope")
+            else:
+                raise NotImplementedError
+        if config.coarse_branch.bin_centers_type != "softplus":
+            if config.coarse_branch.bin_centers_type in ("normed", "hybrid1", "hybrid2"):
+                raise NotImplementedError("only bin_centers_type='softplus' (the shipped configs) is built")
+            raise ValueError("bin_centers_type should be one of 'normed', 'softplus', 'hybrid1', 'hybrid2'")
+        self.resizer = Resizer(self.patch_process_shape[1], self.patch_process_shape[0], 14)
+        self.spec = patchfusion_spec(config)
+        _build_param_tree(self, self.spec)
+        self.consistency_training = False
+        self.compute_dtype = _DTYPES[compute_dtype or config.get("compute_dtype", "fp32")]
+        self.shard_patches = shard_patches
+        self._ops = ops
+        self._engine = None
+        self._coarse_state = None
+        if config.get("load_branch", False) and config.get("pretrain_model"):
+            for prefix, path in zip(("coarse_branch.", "fine_branch."), config.pretrain_model):
+                if path:
+                    sd = torch.load(path, map_location='cpu')['model_state_dict']
+                    self.load_state_dict({prefix + k: v for k, v in sd.items()}, strict=False)
+
+    # ------------------------------------------------------------------ reference helper surface
+    def prepare_tile_cfg(self, image_raw_shape, patch_split_num):
+        return tiling.prepare_tile_cfg(self.patch_process_shape, image_raw_shape, patch_split_num)
+
+    def load_dict(self, dict):
+        return self.load_state_dict(dict, strict=False)
+
+    def load_state_dict(self, *a, **k):
+        self._engine = None
+        return super().load_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._engine = None
+        return super()._apply(fn, *a, **k)
+
+    def get_save_dict(self):
+        return OrderedDict((k, v) for k, v in self.state_dict().items() if 'coarse_branch' not in k and 'fine_branch' not in k)
+
+    def set_compute_dtype(self, dtype):
+        self.compute_dtype = _DTYPES[dtype]
+        self._engine = None
+
+    # ------------------------------------------------------------------ engine
+    @property
+    def ops(self):
+        if self._ops is None:
+            from .hip_ops import ops   # raises if libpf_hip.so is missing: no fallback
+            self._ops = ops
+        return self._ops
+
+    def _ensure_engine(self):
+        if self._engine is None:
+            from .engine import BranchNet, FusionNet, G2LNet
+            sd = self.state_dict()
+            dev = next(iter(sd.values())).device
+            if self._ops is None and dev.type != "cuda":
+                raise RuntimeError("PatchFusion (MI355X engine) needs the model on a GPU: call .cuda() first")
+            dt, cfg = self.compute_dtype, self.config
+            self._engine = dict(
+                coarse=BranchNet(sd, "coarse_branch.", cfg.coarse_branch, self.patch_process_shape, dt, dev),
+                fine=BranchNet(sd, "fine_branch.", cfg.fine_branch, self.patch_process_shape, dt, dev),
+                g2l=G2LNet(sd, cfg.guided_fusion, dt, dev),
+                fusion=FusionNet(sd, cfg, dt, dev))
+            self._device = dev
+            self._mask_cache = {}
+        return self._engine
+
+    def _mask(self, shape):
+        key = tuple(shape)
+        if key not in self._mask_cache:
+            m = torch.from_numpy(tiling.gaussian_blend_mask(key) + 1e-3).to(self._device)
+            self._mask_cache[key] = m.contiguous()
+        return self._mask_cache[key]
+
+    # ------------------------------------------------------------------ branch-level API
+    @torch.no_grad()
+    def _coarse(self, image_lr, taps=None):
+        nets = self._ensure_engine()
+        depth, feats = nets["coarse"].forward(self.ops, image_lr.contiguous().float(), taps)
+        g2l = nets["g2l"].forward(self.ops, feats)        # patch invariant -> once per image (exact)
+        self._coarse_state = dict(depth=depth.view(depth.shape[0], 1, *depth.shape[1:]), feats=feats, g2l=g2l)
+        return self._coarse_state
+
+    def coarse_forward(self, image_lr):
+        """-> (coarse_prediction [1,1,h,w] f32, six coarse feature maps NCHW f32) like patchfusion.py:189-206"""
+        st = self._coarse(image_lr)
+        return st["depth"], [self.ops.nhwc_to_nchw(f) for f in st["feats"]]
+
+    def fine_forward(self, image_hr_crop):
+        nets = self._ensure_engine()
+        depth, feats = nets["fine"].forward(self.ops, image_hr_crop.contiguous().float())
+        return depth.unsqueeze(1), [self.ops.nhwc_to_nchw(f) for f in feats]
+
+    @torch.no_grad()
+    def infer_forward(self, imgs_crop, bbox_feat_forward, tile_temp=None, coarse_temp_dict=None, taps=None):
+        """fine branch + fusion for one batch of crops (patchfusion.py:343-356).  ``bbox_feat_forward``
+        [B,5] = (0, x1,y1,x2,y2) in process coordinates.  The coarse state of the current image is the
+        one produced by the last ``coarse_forward`` / ``forward`` call (``tile_temp`` / ``coarse_temp_dict``
+        are accepted for signature compatibility; the ROI crops are recomputed from the boxes in-kernel
+        instead of being materialised P times)."""
+        nets = self._ensure_engine()
+        st = self._coarse_state
+        assert st is not None, "run coarse_forward first"
+        crops = imgs_crop.contiguous().float()
+        rois = bbox_feat_forward.to(device=crops.device, dtype=torch.float32).contiguous()
+        fdepth, ffeats = nets["fine"].forward(self.ops, crops)
+        d = nets["fusion"].forward(self.ops, crops, rois, fdepth, ffeats, st["depth"], st["feats"], st["g2l"], taps)
+        return d.unsqueeze(1)
+
+    # ------------------------------------------------------------------ tiles
+    def _rois(self, boxes, tile_cfg, device):
+        """bboxs * bboxs_feat_factor in float32 exactly like baseline_pretrain.py:275-282 (int32 boxes times
+        a float32 factor tensor), batch index 0."""
+        H, W = tile_cfg['image_raw_shape']
+        ps = self.patch_process_shape
+        fac = torch.tensor([1 / W * ps[1], 1 / H * ps[0], 1 / W * ps[1], 1 / H * ps[0]]).unsqueeze(0)
+        bf = torch.tensor(boxes, dtype=torch.int32) * fac
+        return torch.cat([torch.zeros(len(boxes), 1), bf], dim=-1).to(device).contiguous()
+
+    @torch.no_grad()
+    def _predict_tiles(self, image_hr, tiles, tile_cfg, process_num):
+        """Per-tile depth [P,h,w] f32 for this rank's shard (all tiles when not distributed)."""
+        ops, dev = self.ops, self._device
+        ph, pw = self.patch_process_shape
+        n = len(tiles)
+        rank, world = 0, 1
+        if self.shard_patches and torch.distributed.is_available() and torch.distributed.is_initialized():
+            rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
+        lo, hi = tiling.shard_range(n, rank, world)
+        preds = ops.empty((n, ph, pw), torch.float32, dev)
+        img = image_hr[0].contiguous().float()
+        for s in range(lo, hi, process_num):
+            e = min(s + process_num, hi)
+            boxes = [t['box'] for t in tiles[s:e]]
+            bt = torch.tensor(boxes, dtype=torch.int32).to(dev)
+            crops = ops.empty((e - s, 3, ph, pw), torch.float32, dev)
+            ops.crop_resize(img, bt, crops)
+            d = self.infer_forward(crops, self._rois(boxes, tile_cfg, dev))
+            preds[s:e] = d[:, 0]
+        if world > 1:
+            from .dist import all_gather_shards
+            preds = all_gather_shards(preds, n, world)
+        return preds
+
+    def _stitch(self, preds, tiles, tile_cfg):
+        ops, dev = self.ops, self._device
+        ph, pw = self.patch_process_shape
+        RH, RW = tile_cfg['patch_reensemble_shape']
+        mask = self._mask((ph, pw))
+        init = [i for i, t in enumerate(tiles) if t['phase'] == 'init']
+        pred = ops.zeros((RH, RW), torch.float32, dev)
+        count = ops.zeros((RH, RW), torch.float32, dev)
+        yx = torch.tensor([tiles[i]['paste'] for i in init], dtype=torch.int32).to(dev)
+        ops.stitch_init(pred, count, preds[init[0]:init[-1] + 1].contiguous(), mask, yx)
+        avg = ops.empty((RH, RW), torch.float32, dev)
+        ops.stitch_finish_init(avg, pred, count)
+        resized = False
+        for i, t in enumerate(tiles):
+            if t['phase'] == 'regular':
+                ops.stitch_update(avg, count, preds[i], mask, t['paste'][0], t['paste'][1])
+            elif t['phase'] == 'random':
+                if not resized:   # RunningAverageMap.resize (utils.py:32-36): avg nearest, count bilinear
+                    H, W = tile_cfg['image_raw_shape']
+                    a2, c2 = ops.empty((H, W), torch.float32, dev), ops.empty((H, W), torch.float32, dev)
+                    ops.resize_nearest_f32(avg, a2)
+                    ops.resize_bilinear_f32(count, c2)
+                    avg, count = a2, c2
+                    raw_mask = self._mask(tile_cfg['patch_raw_shape'])
+                    resized = True
+                ops.stitch_update(avg, count, preds[i], raw_mask, t['paste'][0], t['paste'][1])
+        return avg
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, mode, image_lr, image_hr, depth_gt=None, crops_image_hr=None, crop_depths=None, bboxs=None,
+                tile_cfg=None, cai_mode='m1', process_num=4):
+        if mode == 'train':
+            raise NotImplementedError("training forward is out of scope of the MI355X inference engine")
+        if tile_cfg is None:
+            tile_cfg = self.tile_cfg
+        else:
+            tile_cfg = self.prepare_tile_cfg(tile_cfg['image_raw_shape'], tile_cfg['patch_split_num'])
+        assert image_hr.shape[0] == 1
+        self._ensure_engine()
+        self._coarse(image_lr)
+        tiles = tiling.tile_schedule(tile_cfg, self.patch_process_shape, cai_mode, process_num)
+        preds = self._predict_tiles(image_hr, tiles, tile_cfg, process_num)
+        avg = self._stitch(preds, tiles, tile_cfg)
+        if cai_mode[0] == 'r' and not any(t['phase'] == 'random' for t in tiles):
+            # r<N> with N < process_num: the reference still resizes the map to the raw resolution
+            H, W = tile_cfg['image_raw_shape']
+            a2 = self.ops.empty((H, W), torch.float32, self._device)
+            self.ops.resize_nearest_f32(avg, a2)
+            avg = a2
+        depth = avg.unsqueeze(0).unsqueeze(0)
+        return depth, {'rgb': image_lr, 'depth_pred': depth, 'depth_gt': depth_gt}

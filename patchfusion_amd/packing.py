@@ -1,0 +1,128 @@
+"""Weight packing for the gfx950 kernels (host side, runs once at load time).
+
+Reference checkpoints store PyTorch layouts ([Cout,Cin,KH,KW] convs, [out,in] linears,
+[Cin,Cout,k,k] transposed convs, BatchNorm running statistics).  The implicit-GEMM kernel
+(csrc/igemm.hip) wants, per layer, a row-major [rows][Kpad] matrix in the compute dtype with
+K ordered (ky, kx, c) over the channel layout of the NHWC *buffer* it will read (which may be a
+concat buffer with padded / permuted channels), zero padded to the 128-byte K chunk, plus float
+bias / per-channel scale vectors.  Everything here is exact re-arrangement except the BatchNorm
+fold (eval-mode affine folded into weights and bias, guided_fusion_model.py:59-66).
+"""
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class PackedConv:
+    w: torch.Tensor                 # [rows, Kpad] compute dtype
+    bias: Optional[torch.Tensor]    # float32 [>= cout] or None
+    scale: Optional[torch.Tensor]   # float32 [>= cout] or None
+    KH: int
+    KW: int
+    cin: int                        # valid input channels of the buffer (multiple of 8)
+    cout: int                       # channels stored (multiple of 4); GEMM N
+    cout_real: int
+    shuffle: int = 1                # s for ConvTranspose2d(kernel=stride=s)
+
+    def to(self, device):
+        self.w = self.w.to(device)
+        if self.bias is not None:
+            self.bias = self.bias.to(device)
+        if self.scale is not None:
+            self.scale = self.scale.to(device)
+        return self
+
+
+def k_chunk(dtype):
+    return 64 if dtype == torch.bfloat16 else 32
+
+
+def pack_conv(weight, bias=None, *, dtype, cin_map=None, cin_total=None, scale=None, bn=None, bn_eps=1e-5):
+    """weight [Cout, Cin, KH, KW] (or [Cout, Cin] for nn.Linear).  ``cin_map``: list of
+    (src_start, length, dst_start) placing original input channels into the buffer's channel axis;
+    ``cin_total``: number of valid buffer channels (multiple of 8)."""
+    w = weight.detach().float().cpu()
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    cout, cin, KH, KW = w.shape
+    b = None if bias is None else bias.detach().float().cpu().clone()
+    if bn is not None:                                       # fold eval-mode BatchNorm
+        g, beta, mean, var = [t.detach().float().cpu() for t in bn]
+        f = g / torch.sqrt(var + bn_eps)
+        w = w * f.view(-1, 1, 1, 1)
+        b = (beta - mean * f) if b is None else (b - mean) * f + beta
+    if cin_map is None:
+        cin_map = [(0, cin, 0)]
+    if cin_total is None:
+        cin_total = round_up(max(d + n for _, n, d in cin_map), 8)
+    assert cin_total % 8 == 0
+    cout_store = round_up(cout, 4)
+    rows = round_up(cout_store, 16)
+    wk = torch.zeros(rows, KH, KW, cin_total)
+    for s0, n, d0 in cin_map:
+        wk[:cout, :, :, d0:d0 + n] = w[:, s0:s0 + n].permute(0, 2, 3, 1)
+    K = KH * KW * cin_total
+    Kpad = round_up(K, k_chunk(dtype))
+    wp = torch.zeros(rows, Kpad)
+    wp[:, :K] = wk.reshape(rows, K)
+    bp = None
+    if b is not None:
+        bp = torch.zeros(rows)
+        bp[:cout] = b
+    sp = None
+    if scale is not None:
+        sp = torch.zeros(rows)
+        sp[:cout] = scale.detach().float().cpu()
+    return PackedConv(wp.to(dtype).contiguous(), bp, sp, KH, KW, cin_total, cout_store, cout)
+
+
+def pack_conv_transpose(weight, bias, *, dtype):
+    """nn.ConvTranspose2d(kernel=stride=s, padding=0) (dpt.py:41-52): weight [Cin, Cout, s, s].
+    out[b, y*s+dy, x*s+dx, co] = bias[co] + sum_ci x[b,y,x,ci] * weight[ci,co,dy,dx]  -> a GEMM with
+    N = s*s*Cout rows ordered (dy, dx, co) and a pixel-shuffle store."""
+    w = weight.detach().float().cpu()
+    cin, cout, s, s2 = w.shape
+    assert s == s2 and cout % 4 == 0 and cin % 8 == 0
+    rows_real = s * s * cout
+    rows = round_up(rows_real, 16)
+    Kpad = round_up(cin, k_chunk(dtype))
+    wp = torch.zeros(rows, Kpad)
+    wp[:rows_real, :cin] = w.permute(2, 3, 1, 0).reshape(rows_real, cin)
+    bp = torch.zeros(round_up(cout, 16))
+    bp[:cout] = bias.detach().float().cpu()
+    return PackedConv(wp.to(dtype).contiguous(), bp, None, 1, 1, cin, rows_real, rows_real, shuffle=s)
+
+
+def unpack_conv(pc: PackedConv):
+    """Inverse of pack_conv for test back-ends: returns weight [cout, cin, KH, KW] float32 over the
+    buffer's channel axis (tests/fake_ops.py uses it to drive F.conv2d with the PACKED weights, so the
+    packing itself is covered by the CPU wiring tests)."""
+    K = pc.KH * pc.KW * pc.cin
+    w = pc.w.float()[:pc.cout, :K].reshape(pc.cout, pc.KH, pc.KW, pc.cin).permute(0, 3, 1, 2).contiguous()
+    return w
+
+
+def vit_pos_embed(pos_embed, th, tw):
+    """interpolate_pos_encoding (vision_transformer.py:179-210): bicubic resample of the stored
+    37x37 grid to (th, tw) with the +0.1 offset passed through ``scale_factor``.  It depends only on
+    the weights and the (fixed) process shape, so it is evaluated ONCE on the host at load time
+    instead of in every forward like the reference does."""
+    import torch.nn.functional as F
+    pos = pos_embed.detach().float().cpu()
+    n = pos.shape[1] - 1
+    g = int(math.sqrt(n))
+    if th * tw == n and th == tw:
+        return pos[0].contiguous()
+    dim = pos.shape[-1]
+    grid = pos[:, 1:].reshape(1, g, g, dim).permute(0, 3, 1, 2)
+    grid = F.interpolate(grid, scale_factor=(float(th + 0.1) / g, float(tw + 0.1) / g), mode="bicubic", antialias=False)
+    assert grid.shape[-2] == th and grid.shape[-1] == tw
+    grid = grid.permute(0, 2, 3, 1).reshape(-1, dim)
+    return torch.cat([pos[0, :1], grid], dim=0).contiguous()           # [1 + th*tw, D]

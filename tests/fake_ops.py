@@ -1,0 +1,258 @@
+"""TEST INFRASTRUCTURE ONLY.  A plain-PyTorch (fp32 math) implementation of the op set that
+patchfusion_amd.hip_ops exposes, with identical signatures and buffer conventions.
+
+Two uses:
+  * ``-m "not gpu"``: drive patchfusion_amd.engine on CPU to validate wiring + weight packing against the
+    oracle (no HIP kernel involved -- this is NOT a product path; the product only accepts hip_ops);
+  * ``-m gpu``: the per-op reference each hand-written HIP kernel is compared against.
+"""
+import torch
+import torch.nn.functional as F
+
+from oracle import third_party as tp
+from patchfusion_amd.packing import unpack_conv
+
+
+def _as4(t):
+    if t.dim() == 2:
+        return t.unsqueeze(0).unsqueeze(0)
+    if t.dim() == 3:
+        return t.unsqueeze(0)
+    return t
+
+
+def _act(v, act):
+    if act in (None, "none"):
+        return v
+    if act == "relu":
+        return F.relu(v)
+    if act == "gelu":
+        return F.gelu(v)
+    if act == "softplus":
+        return F.softplus(v)
+    raise ValueError(act)
+
+
+class FakeOps:
+    name = "fake"
+
+    @staticmethod
+    def empty(shape, dtype, device):
+        # NaN-fill so that reads of never-written channels are caught by the wiring tests
+        return torch.full(shape, float("nan"), dtype=dtype, device=device)
+
+    @staticmethod
+    def zeros(shape, dtype, device):
+        return torch.zeros(shape, dtype=dtype, device=device)
+
+    @staticmethod
+    def conv(x, pw, y, stride=1, pad=0, act=None, relu_in=False, res=None, res2=None):
+        x4, y4 = _as4(x), _as4(y)
+        w = unpack_conv(pw).to(x4.device)
+        xin = x4[..., :pw.cin].float().permute(0, 3, 1, 2)
+        if relu_in:
+            xin = F.relu(xin)
+        s = pw.shuffle
+        v = F.conv2d(xin, w, None, stride=stride, padding=pad)                      # [B, N, OH, OW]
+        if s > 1:
+            B, N, OH, OW = v.shape
+            ct = N // (s * s)
+            v = v.view(B, s, s, ct, OH, OW).permute(0, 3, 4, 1, 5, 2).reshape(B, ct, OH * s, OW * s)
+        n = v.shape[1]
+        if pw.bias is not None:
+            v = v + pw.bias[:n].to(v.device).view(1, -1, 1, 1)
+        v = _act(v, act)
+        if pw.scale is not None:
+            v = v * pw.scale[:n].to(v.device).view(1, -1, 1, 1)
+        v = v.permute(0, 2, 3, 1)
+        if res is not None:
+            v = v + _as4(res)[..., :n].float()
+        if res2 is not None:
+            v = v + _as4(res2)[..., :n].float()
+        y4[..., :n] = v.to(y4.dtype)
+        return y
+
+    @staticmethod
+    def patch_im2col(img, out):
+        B, _, H, W = img.shape
+        mean = torch.tensor([0.485, 0.456, 0.406], device=img.device).view(1, 3, 1, 1)
+        std = torch.tensor([0.229, 0.224, 0.225], device=img.device).view(1, 3, 1, 1)
+        x = (img - mean) / std
+        th, tw = H // 14, W // 14
+        p = x.view(B, 3, th, 14, tw, 14).permute(0, 2, 4, 3, 5, 1).reshape(B * th * tw, 588)
+        out[:, :588] = p.to(out.dtype)
+        out[:, 588:] = 0
+
+    @staticmethod
+    def assemble_tokens(emb, tokens, cls, pos):
+        B, S, D = tokens.shape
+        tokens[:, 0] = (cls + pos[0]).to(tokens.dtype)
+        tokens[:, 1:] = (emb.view(B, S - 1, D).float() + pos[1:]).to(tokens.dtype)
+
+    @staticmethod
+    def layernorm(x, y, g, b, eps, batches=1, in_rows_per_batch=None, in_row_offset=0, out_rows_per_batch=None):
+        D = x.shape[-1]
+        xf = x.reshape(-1, D).float()
+        if in_rows_per_batch is not None:
+            xf = xf.view(batches, in_rows_per_batch, D)[:, in_row_offset:in_row_offset + out_rows_per_batch].reshape(-1, D)
+        v = F.layer_norm(xf, (D,), g, b, eps)
+        y.view(-1, D)[:] = v.to(y.dtype)
+
+    @staticmethod
+    def vit_attention(qkv, out, B, S, heads):
+        D = qkv.shape[1] // 3
+        q, k, v = qkv.float().view(B, S, 3, heads, D // heads).permute(2, 0, 3, 1, 4)
+        a = ((q * (D // heads) ** -0.5) @ k.transpose(-2, -1)).softmax(dim=-1)
+        out[:] = (a @ v).transpose(1, 2).reshape(B * S, D).to(out.dtype)
+
+    @staticmethod
+    def swin_ln_partition(x, xw, g, b, eps, shift):
+        B, H, W, C = x.shape
+        v = F.layer_norm(x.float(), (C,), g, b, eps)
+        pr, pb = (12 - W % 12) % 12, (12 - H % 12) % 12
+        v = F.pad(v, (0, 0, 0, pr, 0, pb))
+        if shift > 0:
+            v = torch.roll(v, shifts=(-shift, -shift), dims=(1, 2))
+        Hp, Wp = H + pb, W + pr
+        v = v.view(B, Hp // 12, 12, Wp // 12, 12, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, C)
+        xw[:] = v.to(xw.dtype)
+
+    @staticmethod
+    def swin_window_attention(qkv, out, bias_table, B, Hp, Wp, C, heads, shift):
+        from oracle.pf_oracle import swin_shift_mask
+        from patchfusion_amd.spec import relative_position_index
+        nW = qkv.shape[0] // 144
+        hd = C // heads
+        q, k, v = qkv.float().view(nW, 144, 3, heads, hd).permute(2, 0, 3, 1, 4)
+        attn = (q * hd ** -0.5) @ k.transpose(-2, -1)
+        idx = relative_position_index().to(qkv.device).view(-1)
+        attn = attn + bias_table[idx].view(144, 144, heads).permute(2, 0, 1).unsqueeze(0)
+        if shift > 0:
+            mask = swin_shift_mask(Hp, Wp, 12, shift, qkv.device)
+            attn = attn.view(B, nW // B, heads, 144, 144) + mask.unsqueeze(1).unsqueeze(0)
+            attn = attn.view(-1, heads, 144, 144)
+        attn = attn.softmax(dim=-1)
+        out[:] = (attn @ v).transpose(1, 2).reshape(nW * 144, C).to(out.dtype)
+
+    @staticmethod
+    def swin_unpartition_add(proj, shortcut, y, shift):
+        B, H, W, C = shortcut.shape
+        Hp, Wp = (H + 11) // 12 * 12, (W + 11) // 12 * 12
+        v = proj.float().view(B, Hp // 12, Wp // 12, 12, 12, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, C)
+        if shift > 0:
+            v = torch.roll(v, shifts=(shift, shift), dims=(1, 2))
+        y[..., :C] = (shortcut.float() + v[:, :H, :W]).to(y.dtype)
+
+    @staticmethod
+    def add_rowwise(x, pos):
+        x[:] = (x.float() + pos.unsqueeze(0)).to(x.dtype)
+
+    @staticmethod
+    def resize(x, y, add=None, dtype=None):
+        x4, y4 = _as4(x), _as4(y)
+        C = x4.shape[-1]
+        v = F.interpolate(x4.float().permute(0, 3, 1, 2), size=y4.shape[1:3], mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+        if add is not None:
+            v = _as4(add)[..., :C].float() + v
+        y4[..., :C] = v.to(y4.dtype)
+
+    @staticmethod
+    def crop_resize(img, boxes, out):
+        P, _, oh, ow = out.shape
+        for p, (x0, y0, x1, y1) in enumerate(boxes.tolist()):
+            out[p] = F.interpolate(img[None, :, y0:y1, x0:x1], size=(oh, ow), mode="bilinear", align_corners=True)[0]
+
+    @staticmethod
+    def roi_align_depth(feat, rois, y, spatial_scale):
+        y[:] = tp.roi_align(feat, rois, y.shape[2:], spatial_scale, aligned=True)
+
+    @staticmethod
+    def roi_align(feat, rois, y, spatial_scale, dtype=None):
+        C = feat.shape[-1]
+        v = tp.roi_align(feat.float().permute(0, 3, 1, 2), rois, y.shape[1:3], spatial_scale, aligned=True)
+        y[..., :C] = v.permute(0, 2, 3, 1).to(y.dtype)
+
+    @staticmethod
+    def maxpool2(x, y):
+        C = x.shape[-1]
+        y[..., :C] = F.max_pool2d(x.float().permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).to(y.dtype)
+
+    @staticmethod
+    def copy_channels(x, y):
+        x4, y4 = _as4(x), _as4(y)
+        y4[..., :x4.shape[-1]] = x4.to(y4.dtype)
+
+    @staticmethod
+    def pack_fusion_input(cdepth, fdepth, crops, y):
+        B = y.shape[0]
+        y[..., 0] = cdepth.reshape(B, *y.shape[1:3]).to(y.dtype)
+        y[..., 1] = fdepth.reshape(B, *y.shape[1:3]).to(y.dtype)
+        y[..., 2:5] = crops.permute(0, 2, 3, 1).to(y.dtype)
+        y[..., 5:] = 0
+
+    @staticmethod
+    def nhwc_to_nchw(x, Cc=None):
+        Cc = Cc or x.shape[-1]
+        return x[..., :Cc].float().permute(0, 3, 1, 2).contiguous()
+
+    @staticmethod
+    def attractor(A, n_attr, b_prev, out):
+        h, w = out.shape[1:3]
+        c = F.interpolate(b_prev.permute(0, 3, 1, 2), size=(h, w), mode="bilinear", align_corners=True)   # [B,nb,h,w]
+        a = A[..., :n_attr].permute(0, 3, 1, 2)
+        dx = a.unsqueeze(2) - c.unsqueeze(1)
+        out[:] = (c + (dx / (1 + 300.0 * dx.pow(2))).mean(dim=1)).permute(0, 2, 3, 1)
+
+    @staticmethod
+    def logbinom_depth(pt, centers, depth, min_temp, max_temp):
+        from oracle.pf_oracle import up
+        B, h, w = depth.shape
+        nb = centers.shape[-1]
+        q = pt[..., :4] + 1e-4
+        p = q[..., 0] / (q[..., 0] + q[..., 1])
+        t = q[..., 2] / (q[..., 2] + q[..., 3])
+        t = ((max_temp - min_temp) * t + min_temp).unsqueeze(1)
+        x = p.unsqueeze(1)
+        om = torch.clamp(1 - x, 1e-4, 1)
+        x = torch.clamp(x, 1e-4, 1)
+        k = torch.arange(nb, device=pt.device, dtype=torch.float32).view(1, -1, 1, 1)
+        eps = 1e-7
+        n_, k_ = (nb - 1) + eps, k + eps
+        logc = n_ * torch.log(torch.tensor(n_)) - k_ * torch.log(k_) - (n_ - k_) * torch.log(n_ - k_ + eps)
+        yk = logc + k * torch.log(x) + (nb - 1 - k) * torch.log(om)
+        probs = torch.softmax(yk / t, dim=1)
+        c = up(centers.permute(0, 3, 1, 2), (h, w))
+        depth[:] = (probs * c).sum(dim=1)
+
+    @staticmethod
+    def stitch_init(pred, count, depth, mask, yx):
+        P, ph, pw = depth.shape
+        for p, (y0, x0) in enumerate(yx.tolist()):
+            pred[y0:y0 + ph, x0:x0 + pw] = depth[p] * mask
+            count[y0:y0 + ph, x0:x0 + pw] = mask
+
+    @staticmethod
+    def stitch_finish_init(avg, pred, count):
+        avg[:] = pred / count
+
+    @staticmethod
+    def stitch_update(avg, count, depth, mask, y0, x0):
+        ph, pw = mask.shape
+        d = depth
+        if tuple(depth.shape) != (ph, pw):
+            d = F.interpolate(depth[None, None], (ph, pw))[0, 0]
+        a = avg[y0:y0 + ph, x0:x0 + pw]
+        c = count[y0:y0 + ph, x0:x0 + pw]
+        avg[y0:y0 + ph, x0:x0 + pw] = (d * mask + c * a) / (c + mask)
+        count[y0:y0 + ph, x0:x0 + pw] = c + mask
+
+    @staticmethod
+    def resize_nearest_f32(x, y):
+        y[:] = F.interpolate(x[None, None], size=tuple(y.shape))[0, 0]
+
+    @staticmethod
+    def resize_bilinear_f32(x, y):
+        y[:] = F.interpolate(x[None, None], size=tuple(y.shape), mode="bilinear", align_corners=True)[0, 0]
+
+
+ops = FakeOps()

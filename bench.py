@@ -1,0 +1,160 @@
+"""Headline benchmark: PatchFusion tiled inference, Depth-Anything ViT-L, 4K image, P=16 tiles
+(BASELINE.json configs[2]) on N MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (coarse branch + G2L + per-tile fine branch + guided fusion + stitch)
+over one synthetic 2160x3840 image that is already resident in HBM.  Weak scaling: every GPU processes 16
+tiles per step -- at N GPUs the image is split into 16*N tiles (4x4, 4x8, 8x8, 8x16) that are sharded over
+the ranks (coarse branch + G2L replicated, no communication) and the per-tile depths are all-gathered over
+RCCL before every rank stitches.  value = tiles processed by all ranks / max-over-ranks wall time.
+
+Rank 0 prints ONE JSON line (contract in the task statement) including
+  roofline     : the dominant kernel (implicit-GEMM 3x3 conv 544->544 @ 8x392x518, the largest single op of
+                 the fusion U-Net) timed live with HIP events on its launch stream, vs the dense MFMA peak
+  cpu_baseline : the oracle (CPU port of the reference, oracle/pf_oracle.py) timed on the host cores for a
+                 bounded sample (one tile = fine branch + fusion) of the same workload  [N=1, rank 0 only]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SPLITS = {1: (4, 4), 2: (4, 8), 4: (8, 8), 8: (8, 16)}
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # MI355X_MICROARCH.md: dense MFMA peaks
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--dtype", default=os.environ.get("PF_BENCH_DTYPE", "bf16"), choices=["bf16", "fp32"])
+    ap.add_argument("--encoder", default="vitl")
+    ap.add_argument("--process-num", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    N = max(world, 1)
+    assert args.gpus == N or world == 1, "launch with torch.distributed.run for --gpus > 1"
+
+    from patchfusion_amd.config import make_config
+    from patchfusion_amd.model import PatchFusion
+    from patchfusion_amd.spec import patchfusion_spec, synthetic_state_dict
+
+    raw = (2160, 3840)
+    split = SPLITS.get(N, (4, 4))
+    cfg = make_config(args.encoder, (392, 518), raw, split)
+    sd = synthetic_state_dict(patchfusion_spec(cfg), 0)
+    model = PatchFusion(cfg, compute_dtype=args.dtype).eval()
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    img = torch.rand(1, 3, *raw, generator=torch.Generator().manual_seed(1234)).to(dev)
+    lr = model.resizer(img)
+    P = split[0] * split[1]
+
+    def step():
+        d, _ = model(mode="infer", image_lr=lr, image_hr=img, cai_mode="m1", process_num=args.process_num)
+        return d
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / args.steps * 1e3
+    value = P * args.steps / dt
+
+    out = {
+        "metric": "patches/sec (DepthAnything-ViT-L PatchFusion, 4K image, P=16 tiles per GPU)",
+        "value": round(value, 3), "unit": "patches/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 3), "ms_per_4k_image": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"Depth-Anything-{args.encoder}14 PatchFusion, 2160x3840 synthetic RGB, "
+                               f"{split[0]}x{split[1]} regular tiling (cai_mode m1, {P} tiles = 16 per GPU), process_num={args.process_num}, "
+                               "random-init weights (BASELINE.json configs[2] at N=1)",
+                   "parallelism": f"patch-sharded x{N}, coarse+G2L replicated, RCCL all_gather of tile depths" if N > 1 else "single GPU"},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        out["roofline"] = roofline(args.dtype, dev)
+    if rank == 0 and N == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, sd, img.cpu())
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def roofline(dtype, dev):
+    """Dominant kernel: conv_igemm_kernel on the fusion U-Net's 3x3 conv 544->544 @ [8,392,518] (vitl):
+    algorithmic FLOPs = 2 * 8*392*518 * 9*544 * 544 per launch."""
+    from patchfusion_amd import packing as pk
+    from patchfusion_amd.hip_ops import ops
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    B, H, W, C = 8, 392, 518, 544
+    w = torch.randn(C, C, 3, 3) / (9 * C) ** 0.5
+    pw = pk.pack_conv(w, torch.zeros(C), dtype=tdt).to(dev)
+    x = torch.randn(B, H, W, C, device=dev).to(tdt)
+    y = torch.empty(B, H, W, C, device=dev, dtype=tdt)
+    ms = ops.conv(x, pw, y, pad=1, act="relu", _timed=5)
+    flops = 2.0 * B * H * W * 9 * C * C
+    ach = flops / (ms * 1e-3) / 1e12
+    peak = PEAK_TFLOPS[dtype]
+    return {"bound": "mfma", "kernel": "conv_igemm_kernel 3x3 544->544 @ 8x392x518 (GuidedFusion up-conv, largest op)",
+            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "traffic": None}
+
+
+def cpu_baseline(cfg, sd, img):
+    """The oracle (CPU restatement of the reference, kind 'port') on the host cores: one tile of the SAME
+    vitl workload (fine branch + fusion_forward, G2L hoisted), coarse pass untimed."""
+    from oracle import pf_oracle
+    torch.set_num_threads(os.cpu_count() or 1)
+    orc = pf_oracle.Oracle(cfg, sd)
+    with torch.no_grad():
+        lr = orc.resizer(img)
+        orc.coarse_depth, orc.coarse_feats = pf_oracle.branch_forward(sd, "coarse_branch.", lr, cfg["coarse_branch"])
+        orc.g2l = pf_oracle.g2l_all(sd, orc.coarse_feats)
+        tile_cfg = pf_oracle.prepare_tile_cfg(orc.ps, cfg["image_raw_shape"], cfg["patch_split_num"])
+        hr, wr = tile_cfg["patch_raw_shape"]
+        crop = orc.resizer(img[:, :, :hr, :wr])
+        box = torch.tensor([[0, 0, wr, hr]]).int()
+        t0 = time.perf_counter()
+        orc._predict(crop, box, tile_cfg, 1)
+        dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 tile (fine branch + fusion, G2L hoisted) of the same DA-vitl 392x518 workload, {dt:.1f} s CPU"}
+
+
+if __name__ == "__main__":
+    main()

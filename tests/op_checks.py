@@ -1,0 +1,341 @@
+"""TEST INFRASTRUCTURE: per-op parity checks of the hand-written HIP kernels (through the C ABI,
+patchfusion_amd.hip_ops) against the plain-PyTorch fp32 reference of the same op (tests/fake_ops.py).
+
+Each check is ``name -> callable(dtype) -> (err, tol, info)`` where err = max|hip - ref| / max(1, max|ref|).
+Used by tests/test_hip_ops_gpu.py (pytest -m gpu) and tools/gpu_selfcheck.py (one subprocess per
+check so that a faulting kernel cannot hide the others).
+"""
+import torch
+
+from patchfusion_amd import packing as pk
+from tests.fake_ops import ops as ref_ops
+
+DEV = "cuda"
+
+
+def hip():
+    from patchfusion_amd.hip_ops import ops
+    return ops
+
+
+def _rand(shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+def _tol(dtype, f32=2e-4, bf16=2e-2):
+    return f32 if dtype == torch.float32 else bf16
+
+
+def _err(a, b):
+    a, b = a.float(), b.float()
+    if not torch.isfinite(a).all():
+        return float("inf")
+    return float((a - b).abs().max() / max(1.0, float(b.abs().max())))
+
+
+def _conv_case(dtype, B, H, W, cin, cout, k, stride=1, pad=0, act=None, relu_in=False, res=False, res2=False, bias=True,
+               scale=False, x_extra=0, y_extra=0, out_f32=False, inplace=False, cin_real=None, seed=0):
+    cin_real = cin_real or cin
+    w = torch.randn(cout, cin_real, k, k, generator=torch.Generator().manual_seed(seed)) / (cin_real * k * k) ** 0.5
+    b = torch.randn(cout, generator=torch.Generator().manual_seed(seed + 1)) if bias else None
+    sc = (0.5 + torch.rand(cout, generator=torch.Generator().manual_seed(seed + 2))) if scale else None
+    pw = pk.pack_conv(w, b, dtype=dtype, cin_total=cin, scale=sc).to(DEV)
+    xb = _rand((B, H, W, cin + x_extra), dtype, seed + 3)
+    x = xb[..., x_extra // 2: x_extra // 2 + cin] if x_extra else xb
+    if x_extra and (x_extra // 2) % 8:
+        raise ValueError("x_extra/2 must be a multiple of 8")
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    ydt = torch.float32 if out_f32 else dtype
+    outs = []
+    r1 = _rand((B, OH, OW, pw.cout), dtype, seed + 4) if res else None
+    r2 = _rand((B, OH, OW, pw.cout), dtype, seed + 5) if res2 else None
+    for o in (hip(), ref_ops):
+        yb = torch.zeros((B, OH, OW, pw.cout + y_extra), dtype=ydt, device=DEV)
+        y = yb[..., y_extra // 2: y_extra // 2 + pw.cout] if y_extra else yb
+        rr = r1
+        if inplace:
+            y.copy_(r1)
+            rr = y
+        o.conv(x, pw, y, stride=stride, pad=pad, act=act, relu_in=relu_in, res=rr, res2=r2)
+        outs.append(yb.clone())
+    torch.cuda.synchronize()
+    return _err(outs[0], outs[1]), _tol(dtype), f"conv B{B} {H}x{W} {cin}->{cout} k{k}"
+
+
+def conv_gemm_qkv(dt):
+    return _conv_case(dt, 1, 1, 2 * 1037, 384, 1152, 1)
+
+
+def conv_gemm_fc2_inplace(dt):
+    return _conv_case(dt, 1, 1, 1037, 1536, 384, 1, scale=True, res=True, inplace=True)
+
+
+def conv_gemm_gelu(dt):
+    return _conv_case(dt, 1, 1, 777, 384, 1536, 1, act="gelu")
+
+
+def conv3x3_rcu(dt):
+    return _conv_case(dt, 2, 28, 37, 64, 64, 3, pad=1, relu_in=True, res=True, res2=True)
+
+
+def conv3x3_stride2(dt):
+    return _conv_case(dt, 2, 28, 37, 384, 384, 3, stride=2, pad=1)
+
+
+def conv3x3_small_cin(dt):
+    return _conv_case(dt, 2, 40, 52, 8, 32, 3, pad=1, act="relu", cin_real=5)
+
+
+def conv3x3_n160_views(dt):
+    return _conv_case(dt, 1, 30, 41, 160, 160, 3, pad=1, act="relu", x_extra=32, y_extra=32)
+
+
+def conv3x3_n544(dt):
+    return _conv_case(dt, 1, 24, 31, 544, 544, 3, pad=1, act="relu")
+
+
+def conv1x1_cout1_f32out(dt):
+    return _conv_case(dt, 2, 17, 23, 128, 1, 1, act="softplus", out_f32=True)
+
+
+def conv1x1_cout80(dt):
+    return _conv_case(dt, 1, 33, 47, 168, 80, 1, act="gelu")
+
+
+def conv1x1_cout16(dt):
+    return _conv_case(dt, 1, 33, 47, 128, 16, 1, act="softplus", out_f32=True)
+
+
+def conv3x3_nobias_48(dt):
+    return _conv_case(dt, 1, 32, 44, 48, 64, 3, pad=1, bias=False)
+
+
+def conv_transpose(dt):
+    errs = []
+    for s, cin in ((4, 48), (2, 96)):
+        w = torch.randn(cin, cin, s, s, generator=torch.Generator().manual_seed(s)) / cin ** 0.5
+        b = torch.randn(cin, generator=torch.Generator().manual_seed(s + 1))
+        pw = pk.pack_conv_transpose(w, b, dtype=dt).to(DEV)
+        x = _rand((2, 8, 11, cin), dt, 7)
+        ys = []
+        for o in (hip(), ref_ops):
+            y = torch.zeros((2, 8 * s, 11 * s, cin), dtype=dt, device=DEV)
+            o.conv(x, pw, y)
+            ys.append(y)
+        ref = torch.nn.functional.conv_transpose2d(x.float().permute(0, 3, 1, 2), w.to(dt).float().to(DEV), b.to(DEV), stride=s).permute(0, 2, 3, 1)
+        errs += [_err(ys[0], ys[1]), _err(ys[1], ref)]
+    torch.cuda.synchronize()
+    return max(errs), _tol(dt), "convT s4,s2"
+
+
+def patch_embed_tokens(dt):
+    img = torch.rand(2, 3, 112, 154, generator=torch.Generator().manual_seed(1)).to(DEV)
+    outs = []
+    cls, pos = _rand((384,), torch.float32, 2), _rand((89, 384), torch.float32, 3)
+    emb = _rand((2 * 88, 384), dt, 4)
+    for o in (hip(), ref_ops):
+        col = torch.zeros((2 * 88, 592), dtype=dt, device=DEV)
+        o.patch_im2col(img, col)
+        tok = torch.zeros((2, 89, 384), dtype=dt, device=DEV)
+        o.assemble_tokens(emb, tok, cls, pos)
+        outs.append((col, tok))
+    torch.cuda.synchronize()
+    return max(_err(outs[0][0], outs[1][0]), _err(outs[0][1], outs[1][1])), _tol(dt, 1e-5, 1e-2), "im2col+tokens"
+
+
+def layernorm(dt):
+    errs = []
+    for D in (384, 1024, 32, 64):
+        x = _rand((2 * 89, D), dt, D, 2.0)
+        g, b = 1 + 0.1 * _rand((D,), torch.float32, 1), 0.1 * _rand((D,), torch.float32, 2)
+        ys = []
+        for o in (hip(), ref_ops):
+            y = torch.zeros((2 * 89, D), dtype=dt, device=DEV)
+            o.layernorm(x, y, g, b, 1e-6)
+            y2 = torch.zeros((2 * 88, D), dtype=dt, device=DEV)
+            o.layernorm(x, y2, g, b, 1e-6, batches=2, in_rows_per_batch=89, in_row_offset=1, out_rows_per_batch=88)
+            ys.append(torch.cat([y, y2]))
+        errs.append(_err(ys[0], ys[1]))
+    torch.cuda.synchronize()
+    return max(errs), _tol(dt, 1e-5, 1e-2), "layernorm"
+
+
+def vit_attention(dt):
+    errs = []
+    for B, S, H in ((2, 1037, 6), (1, 89, 16), (3, 64, 2)):
+        qkv = _rand((B * S, 3 * H * 64), dt, S)
+        ys = []
+        for o in (hip(), ref_ops):
+            y = torch.zeros((B * S, H * 64), dtype=dt, device=DEV)
+            o.vit_attention(qkv, y, B, S, H)
+            ys.append(y)
+        errs.append(_err(ys[0], ys[1]))
+    torch.cuda.synchronize()
+    return max(errs), _tol(dt, 1e-4, 2e-2), "vit attention"
+
+
+def swin_ops(dt):
+    errs = []
+    for (B, H, W, C, heads) in ((1, 14, 19, 64, 32), (1, 28, 37, 64, 16), (2, 30, 25, 32, 8), (1, 13, 24, 256, 8), (1, 12, 12, 128, 8), (1, 17, 12, 256, 16), (1, 12, 24, 64, 8)):
+        for shift in (0, 6):
+            Hp, Wp = (H + 11) // 12 * 12, (W + 11) // 12 * 12
+            x = _rand((B, H, W, C), dt, H * W + shift)
+            g, b = 1 + 0.1 * _rand((C,), torch.float32, 1), 0.1 * _rand((C,), torch.float32, 2)
+            nt = B * Hp * Wp
+            qkv = _rand((nt, 3 * C), dt, 5)
+            bt = _rand((529, heads), torch.float32, 6, 0.5)
+            pr = _rand((nt, C), dt, 8)
+            pos = _rand((H * W, C), torch.float32, 9)
+            res = []
+            for o in (hip(), ref_ops):
+                xw = torch.zeros((nt, C), dtype=dt, device=DEV)
+                o.swin_ln_partition(x, xw, g, b, 1e-5, shift)
+                ao = torch.zeros((nt, C), dtype=dt, device=DEV)
+                o.swin_window_attention(qkv, ao, bt, B, Hp, Wp, C, heads, shift)
+                y = torch.zeros((B, H, W, C), dtype=dt, device=DEV)
+                o.swin_unpartition_add(pr, x, y, shift)
+                x2 = x.clone().view(B, H * W, C)
+                o.add_rowwise(x2, pos)
+                res.append((xw, ao, y, x2))
+            errs += [_err(a, c) for a, c in zip(res[0], res[1])]
+    torch.cuda.synchronize()
+    return max(errs), _tol(dt, 1e-4, 2e-2), "swin ops"
+
+
+def resize_ops(dt):
+    errs = []
+    for (h, w, oh, ow, C) in ((14, 19, 28, 37, 64), (49, 64, 56, 74, 32), (224, 296, 392, 518, 8), (12, 16, 14, 19, 128), (8, 11, 8, 11, 64)):
+        x = _rand((2, h, w, C), dt, h)
+        add = _rand((2, oh, ow, C), dt, w)
+        res = []
+        for o in (hip(), ref_ops):
+            buf = torch.zeros((2, oh, ow, C + 16), dtype=dt, device=DEV)
+            o.resize(x, buf[..., 8:8 + C])
+            y2 = torch.zeros((2, oh, ow, C), dtype=dt, device=DEV)
+            o.resize(x, y2, add=add)
+            res.append((buf, y2))
+        errs += [_err(a, c) for a, c in zip(res[0], res[1])]
+    # f32 source -> dt destination (embedding upsample into the CLB buffer) and planar helpers
+    img = torch.rand(3, 96, 130, generator=torch.Generator().manual_seed(5)).to(DEV)
+    boxes = torch.tensor([[0, 0, 65, 48], [65, 48, 130, 96], [13, 7, 78, 55]], dtype=torch.int32, device=DEV)
+    res = []
+    for o in (hip(), ref_ops):
+        out = torch.zeros((3, 3, 28, 42), dtype=torch.float32, device=DEV)
+        o.crop_resize(img, boxes, out)
+        a = torch.rand(40, 52, generator=torch.Generator().manual_seed(6)).to(DEV)
+        n, bl = torch.zeros((96, 130), device=DEV), torch.zeros((96, 130), device=DEV)
+        o.resize_nearest_f32(a, n)
+        o.resize_bilinear_f32(a, bl)
+        res.append((out, n, bl))
+    errs += [_err(a, c) for a, c in zip(res[0], res[1])]
+    torch.cuda.synchronize()
+    return max(errs), _tol(dt, 1e-5, 1e-2), "resize/crop"
+
+
+def roi_ops(dt):
+    errs = []
+    ph = 112
+    feats = [(4, 6, 64), (28, 37, 64), (112, 154, 32)]
+    rois = torch.tensor([[0, 0.0, 0.0, 77.0, 56.0], [0, 77.0, 56.0, 154.0, 112.0], [0, 38.5, 28.0, 115.5, 84.0],
+                         [0, 100.25, 60.5, 177.25, 116.5], [0, -90.0, -70.0, -13.0, -14.0]], device=DEV)
+    for (h, w, C) in feats:
+        f = _rand((1, h, w, C), dt, h)
+        res = []
+        for o in (hip(), ref_ops):
+            y = torch.zeros((5, h, w, 2 * C), dtype=dt, device=DEV)
+            o.roi_align(f, rois, y[..., C:], h / ph)
+            res.append(y)
+        errs.append(_err(res[0], res[1]))
+    # multi-sample bins (roi larger than the output grid) and the planar depth variant
+    f = _rand((2, 16, 16, 8), dt, 3)
+    r2 = torch.tensor([[1, 0.0, 0.0, 16.0, 16.0], [0, 2.0, 3.0, 14.0, 12.0]], device=DEV)
+    d = torch.rand(1, 1, 112, 154, generator=torch.Generator().manual_seed(9)).to(DEV)
+    res = []
+    for o in (hip(), ref_ops):
+        y = torch.zeros((2, 4, 5, 8), dtype=dt, device=DEV)
+        o.roi_align(f, r2, y, 1.0)
+        yd = torch.zeros((5, 1, 112, 154), device=DEV)
+        o.roi_align_depth(d, rois, yd, 1.0)
+        res.append((y, yd))
+    errs += [_err(a, c) for a, c in zip(res[0], res[1])]
+    torch.cuda.synchronize()
+    return max(errs), _tol(dt, 1e-5, 1e-2), "roi_align"
+
+
+def misc_ops(dt):
+    errs = []
+    x = _rand((2, 49, 65, 32), dt, 1)
+    cd, fd = torch.rand(2, 1, 20, 30).to(DEV), torch.rand(2, 20, 30).to(DEV)
+    crops = torch.rand(2, 3, 20, 30).to(DEV)
+    res = []
+    for o in (hip(), ref_ops):
+        y = torch.zeros((2, 24, 32, 32), dtype=dt, device=DEV)
+        o.maxpool2(x, y)
+        c = torch.zeros((2, 49, 65, 64), dtype=dt, device=DEV)
+        o.copy_channels(x, c[..., 32:])
+        p = torch.zeros((2, 20, 30, 8), dtype=dt, device=DEV)
+        o.pack_fusion_input(cd, fd, crops, p)
+        n = o.nhwc_to_nchw(c[..., 32:])
+        res.append((y, c, p, n))
+    errs += [_err(a, c) for a, c in zip(res[0], res[1])]
+    torch.cuda.synchronize()
+    return max(errs), _tol(dt, 1e-6, 1e-2), "maxpool/copy/pack/nchw"
+
+
+def bins_ops(dt):
+    errs = []
+    for n_attr, (hp, wp, h, w) in ((16, (4, 6, 8, 11)), (8, (8, 11, 16, 22)), (1, (32, 44, 64, 88))):
+        A = torch.nn.functional.softplus(_rand((2, h, w, (n_attr + 3) // 4 * 4), torch.float32, n_attr))
+        bp = torch.nn.functional.softplus(_rand((2, hp, wp, 64), torch.float32, 3))
+        res = []
+        for o in (hip(), ref_ops):
+            out = torch.zeros((2, h, w, 64), device=DEV)
+            o.attractor(A, n_attr, bp, out)
+            res.append(out)
+        errs.append(_err(res[0], res[1]))
+    pt = torch.nn.functional.softplus(_rand((2, 56, 77, 4), torch.float32, 5) + torch.tensor([0, 0, -4.0, 1.0], device=DEV))
+    cen = torch.nn.functional.softplus(_rand((2, 32, 44, 64), torch.float32, 6))
+    res = []
+    for o in (hip(), ref_ops):
+        d = torch.zeros((2, 56, 77), device=DEV)
+        o.logbinom_depth(pt, cen, d, 0.0212, 50.0)
+        res.append(d)
+    errs.append(_err(res[0], res[1]))
+    torch.cuda.synchronize()
+    return max(errs), 2e-5, "attractor/logbinom"
+
+
+def stitch_ops(dt):
+    ph, pw = 28, 42
+    depth = torch.rand(6, ph, pw, generator=torch.Generator().manual_seed(1)).to(DEV) + 0.5
+    mask = torch.rand(ph, pw, generator=torch.Generator().manual_seed(2)).to(DEV) + 1e-3
+    yx = torch.tensor([[0, 0], [0, 42], [28, 0], [28, 42]], dtype=torch.int32, device=DEV)
+    rawmask = torch.rand(40, 60, generator=torch.Generator().manual_seed(3)).to(DEV) + 1e-3
+    res = []
+    for o in (hip(), ref_ops):
+        pred, cnt, avg = torch.zeros(56, 84, device=DEV), torch.zeros(56, 84, device=DEV), torch.zeros(56, 84, device=DEV)
+        o.stitch_init(pred, cnt, depth[:4].contiguous(), mask, yx)
+        o.stitch_finish_init(avg, pred, cnt)
+        o.stitch_update(avg, cnt, depth[4], mask, 14, 21)
+        a2, c2 = torch.zeros(80, 120, device=DEV), torch.zeros(80, 120, device=DEV)
+        o.resize_nearest_f32(avg, a2)
+        o.resize_bilinear_f32(cnt, c2)
+        o.stitch_update(a2, c2, depth[5], rawmask, 33, 47)
+        res.append((avg, cnt, a2, c2))
+    errs = [_err(a, c) for a, c in zip(res[0], res[1])]
+    torch.cuda.synchronize()
+    return max(errs), 1e-5, "stitch"
+
+
+CHECKS = {
+    "conv_gemm_qkv": conv_gemm_qkv, "conv_gemm_fc2_inplace": conv_gemm_fc2_inplace, "conv_gemm_gelu": conv_gemm_gelu,
+    "conv3x3_rcu": conv3x3_rcu, "conv3x3_stride2": conv3x3_stride2, "conv3x3_small_cin": conv3x3_small_cin,
+    "conv3x3_n160_views": conv3x3_n160_views, "conv3x3_n544": conv3x3_n544, "conv1x1_cout1_f32out": conv1x1_cout1_f32out,
+    "conv1x1_cout80": conv1x1_cout80, "conv1x1_cout16": conv1x1_cout16, "conv3x3_nobias_48": conv3x3_nobias_48,
+    "conv_transpose": conv_transpose, "patch_embed_tokens": patch_embed_tokens, "layernorm": layernorm,
+    "vit_attention": vit_attention, "swin_ops": swin_ops, "resize_ops": resize_ops, "roi_ops": roi_ops,
+    "misc_ops": misc_ops, "bins_ops": bins_ops, "stitch_ops": stitch_ops,
+}
+F32_ONLY = {"bins_ops", "stitch_ops"}
+DTYPES = {"fp32": torch.float32, "bf16": torch.bfloat16}

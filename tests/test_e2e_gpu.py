@@ -1,0 +1,110 @@
+"""pytest -m gpu: the whole PatchFusion hot path on the MI355X HIP engine (through the C ABI) against
+ (a) the committed golden fixtures generated from the REFERENCE's own Python (tests/golden/*.npz),
+ (b) the oracle restatement (oracle/pf_oracle.py) on the same seeded inputs.
+Stated tolerances on the final metric depth (random-init nets: depth std ~0.01..0.09):
+   fp32 mode: max |d - ref| <= 2e-4 absolute (f32 MFMA = exact fma chain; only summation order differs)
+   bf16 mode: max |d - ref| <= 0.35 * std(ref) and mean |d - ref| <= 0.06 * std(ref)
+"""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pf_oracle
+from patchfusion_amd.config import make_config
+from patchfusion_amd.model import PatchFusion
+from patchfusion_amd.spec import patchfusion_spec, synthetic_state_dict
+
+pytestmark = pytest.mark.gpu
+TINY = ("vits", (112, 154), (448, 616), (2, 2))
+
+
+def build(enc, ps, raw, split, dtype):
+    cfg = make_config(enc, ps, raw, split)
+    sd = synthetic_state_dict(patchfusion_spec(cfg), 0)
+    m = PatchFusion(cfg, compute_dtype=dtype).eval()
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    img = torch.rand(1, 3, *raw, generator=torch.Generator().manual_seed(1234))
+    return cfg, sd, m, img
+
+
+@pytest.mark.parametrize("mode", ["m1", "m2", "r4"])
+def test_tiny_fp32_matches_reference_golden(golden_dir, mode):
+    g = np.load(os.path.join(golden_dir, "tiny_vits.npz"))
+    cfg, sd, m, img = build(*TINY, "fp32")
+    lr = m.resizer(img).cuda()
+    random.seed(5621)
+    d, _ = m(mode="infer", image_lr=lr, image_hr=img.cuda(), cai_mode=mode, process_num=2)
+    ref = g[f"depth_{mode}"]
+    assert tuple(d.shape[2:]) == ref.shape
+    err = np.abs(d[0, 0].cpu().numpy() - ref).max()
+    assert err <= 2e-4, f"{mode}: {err}"
+
+
+def test_tiny_fp32_stage_parity_vs_oracle():
+    cfg, sd, m, img = build(*TINY, "fp32")
+    lr = m.resizer(img)
+    ot, et = {}, {}
+    od, of = pf_oracle.branch_forward(sd, "coarse_branch.", lr, cfg["coarse_branch"], ot)
+    st = m._coarse(lr.cuda(), et)
+    nchw = lambda t: t.float().cpu().permute(0, 3, 1, 2)
+    for k in ("vit_tokens_in", "vit_block0", "vit_block11"):
+        assert (ot[k] - et[k].float().cpu()).abs().max() < 1e-3, k
+    for i, (a, b) in enumerate(zip(of, st["feats"])):
+        assert (a - nchw(b)).abs().max() < 2e-3, i
+    assert (od - st["depth"].cpu()).abs().max() < 2e-4
+    g2l = pf_oracle.g2l_all(sd, of)
+    for i, (a, b) in enumerate(zip(g2l, st["g2l"])):
+        assert (a - nchw(b)).abs().max() < 2e-3, i
+
+
+def test_tiny_bf16_within_stated_tolerance(golden_dir):
+    g = np.load(os.path.join(golden_dir, "tiny_vits.npz"))
+    cfg, sd, m, img = build(*TINY, "bf16")
+    lr = m.resizer(img).cuda()
+    d, _ = m(mode="infer", image_lr=lr, image_hr=img.cuda(), cai_mode="m1", process_num=4)
+    ref = g["depth_m1"]
+    diff = np.abs(d[0, 0].float().cpu().numpy() - ref)
+    assert diff.max() <= 0.35 * ref.std() and diff.mean() <= 0.06 * ref.std(), (diff.max(), diff.mean(), ref.std())
+
+
+def test_full_size_vits_fp32_matches_reference_golden(golden_dir):
+    """392x518 process shape (the shipped configs), 784x1036 image, 2x2 tiles: 8192 sampled outputs of
+    the reference + the coarse depth."""
+    g = np.load(os.path.join(golden_dir, "full_vits.npz"))
+    cfg, sd, m, img = build("vits", (392, 518), (784, 1036), (2, 2), "fp32")
+    lr = m.resizer(img).cuda()
+    random.seed(5621)
+    d, _ = m(mode="infer", image_lr=lr, image_hr=img.cuda(), cai_mode="m1", process_num=4)
+    v = d.flatten().cpu()[torch.from_numpy(g["depth_m1_idx"])].numpy()
+    assert np.abs(v - g["depth_m1_val"]).max() <= 2e-4
+    c = m._coarse_state["depth"].flatten().cpu()[torch.from_numpy(g["coarse_depth_idx"])].numpy()
+    assert np.abs(c - g["coarse_depth_val"]).max() <= 2e-4
+
+
+def test_vitl_patch_batch_vs_oracle_on_gpu():
+    """Depth-Anything ViT-L (the headline model) at the full 392x518 process shape, one fine+fusion batch
+    of 2 tiles, engine (fp32 and bf16) vs the oracle evaluated with torch on the same GPU."""
+    cfg = make_config("vitl", (392, 518), (784, 1036), (2, 2))
+    sd = synthetic_state_dict(patchfusion_spec(cfg), 0)
+    img = torch.rand(1, 3, 784, 1036, generator=torch.Generator().manual_seed(1234)).cuda()
+    sdg = {k: v.cuda() for k, v in sd.items()}
+    orc = pf_oracle.Oracle(cfg, sdg)
+    lr = orc.resizer(img)
+    ref = orc.infer(lr, img, "m1", 2)[0, 0]
+    for dtype, tol_max, tol_mean in (("fp32", 5e-4, 5e-5), ("bf16", None, None)):
+        m = PatchFusion(cfg, compute_dtype=dtype).eval()
+        m.load_state_dict(sd, strict=True)
+        m = m.cuda()
+        d, _ = m(mode="infer", image_lr=lr, image_hr=img, cai_mode="m1", process_num=2)
+        diff = (d[0, 0] - ref).abs()
+        s = float(ref.std())
+        if dtype == "fp32":
+            assert float(diff.max()) <= tol_max and float(diff.mean()) <= tol_mean, (float(diff.max()), float(diff.mean()))
+        else:
+            assert float(diff.max()) <= 0.5 * s and float(diff.mean()) <= 0.08 * s, (float(diff.max()), float(diff.mean()), s)
+        del m
+        torch.cuda.empty_cache()

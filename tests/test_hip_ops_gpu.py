@@ -1,0 +1,26 @@
+"""pytest -m gpu: every hand-written HIP kernel (through the C ABI) against the plain-PyTorch fp32
+reference of the same op, in both compute modes.  Tolerances (relative to max|ref|, floor 1):
+fp32 mode 2e-4 for MFMA ops / 1e-5 for pointwise ops; bf16 mode 2e-2 (bf16 storage rounding 2^-8)."""
+import pytest
+import torch
+
+from tests import op_checks
+
+pytestmark = pytest.mark.gpu
+
+CASES = [(n, d) for n in op_checks.CHECKS for d in ("fp32", "bf16") if not (d == "bf16" and n in op_checks.F32_ONLY)]
+
+
+@pytest.mark.parametrize("name,dt", CASES)
+def test_op(name, dt):
+    assert torch.cuda.is_available()
+    err, tol, info = op_checks.CHECKS[name](op_checks.DTYPES[dt])
+    assert err <= tol, f"{name}[{dt}] {info}: err {err:.3e} > tol {tol:.1e}"
+
+
+def test_native_library_is_loaded_and_used():
+    import patchfusion_amd._lib as L
+    lib = L.load()
+    assert lib.pf_version() >= 1
+    maps = open("/proc/self/maps").read()
+    assert "libpf_hip.so" in maps

@@ -32,6 +32,13 @@ SPLITS = {1: (4, 4), 2: (4, 8), 4: (8, 8), 8: (8, 16)}
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # MI355X_MICROARCH.md: dense MFMA peaks
 
 
+T0 = time.time()
+
+
+def log(msg):
+    print(f"[bench +{time.time() - T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,6 +73,7 @@ def main():
     model = PatchFusion(cfg, compute_dtype=args.dtype).eval()
     model.load_state_dict(sd, strict=True)
     model = model.to(dev)
+    log("model built and on device")
     img = torch.rand(1, 3, *raw, generator=torch.Generator().manual_seed(1234)).to(dev)
     lr = model.resizer(img)
     P = split[0] * split[1]
@@ -79,8 +87,10 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         step()
+        torch.cuda.synchronize()
+        log(f"warmup step {i} done")
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -91,6 +101,7 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+    log(f"timed {args.steps} steps: {dt:.3f}s")
     ms = dt / args.steps * 1e3
     value = P * args.steps / dt
 
@@ -107,6 +118,7 @@ def main():
 
     if rank == 0 and not args.no_roofline:
         out["roofline"] = roofline(args.dtype, dev)
+        log(f"roofline: {out['roofline']}")
     if rank == 0 and N == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, sd, img.cpu())
     if rank == 0:

@@ -148,24 +148,25 @@ def roofline(dtype, dev):
 
 
 def cpu_baseline(cfg, sd, img):
-    """The oracle (CPU restatement of the reference, kind 'port') on the host cores: one tile of the SAME
-    vitl workload (fine branch + fusion_forward, G2L hoisted), coarse pass untimed."""
+    """The oracle (CPU restatement of the reference, kind 'port') on the host cores, bounded sample:
+    ONE fine-branch forward (ZoeDepth branch: ViT-L + DPT + bins head) of one 392x518 tile of the same
+    workload, scaled to patches/s by the algorithmic FLOP share of the branch in one tile
+    (970.1 GF of 4029.9 GF per tile)."""
     from oracle import pf_oracle
-    torch.set_num_threads(os.cpu_count() or 1)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
     orc = pf_oracle.Oracle(cfg, sd)
     with torch.no_grad():
-        lr = orc.resizer(img)
-        orc.coarse_depth, orc.coarse_feats = pf_oracle.branch_forward(sd, "coarse_branch.", lr, cfg["coarse_branch"])
-        orc.g2l = pf_oracle.g2l_all(sd, orc.coarse_feats)
-        tile_cfg = pf_oracle.prepare_tile_cfg(orc.ps, cfg["image_raw_shape"], cfg["patch_split_num"])
-        hr, wr = tile_cfg["patch_raw_shape"]
+        hr, wr = cfg["image_raw_shape"][0] // cfg["patch_split_num"][0], cfg["image_raw_shape"][1] // cfg["patch_split_num"][1]
         crop = orc.resizer(img[:, :, :hr, :wr])
-        box = torch.tensor([[0, 0, wr, hr]]).int()
         t0 = time.perf_counter()
-        orc._predict(crop, box, tile_cfg, 1)
+        pf_oracle.branch_forward(sd, "fine_branch.", crop, cfg["fine_branch"])
         dt = time.perf_counter() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 tile (fine branch + fusion, G2L hoisted) of the same DA-vitl 392x518 workload, {dt:.1f} s CPU"}
+    share = 970.1 / 4029.9
+    log(f"cpu baseline: branch forward {dt:.1f}s on {cores} cores")
+    return {"value": round(share / dt, 5), "unit": "patches/s", "cores": cores, "kind": "port",
+            "sample": f"1 fine-branch forward (ViT-L+DPT+bins head, 970.1 of the 4029.9 GFLOP of one tile) of the same "
+                      f"workload: {dt:.1f} s on {cores} threads, scaled by the FLOP share"}
 
 
 if __name__ == "__main__":

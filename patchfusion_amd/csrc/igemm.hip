@@ -63,19 +63,39 @@ __device__ __forceinline__ void mma_half_f32(const uint4 (&wf)[FN], const uint4 
       }
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+// 256 bytes of zeros: source of every out-of-image / out-of-range 16-byte vector (conv padding, M/N tails)
+__device__ __attribute__((aligned(256))) unsigned int pf_zero_page[64];
+
+// LDS-DMA of one 16-byte vector per lane: LDS[m0_base + lane*16] <- *gsrc.  Issued through inline asm so that
+// hipcc does not serialise it against the ds_reads of the OTHER ring stage (it inserts a conservative
+// s_waitcnt vmcnt(0) before the first ds_read that follows a compiler-visible LDS-DMA).  We count the
+// completions ourselves: one explicit s_waitcnt vmcnt(0) before the barrier that publishes the stage.
+// M0 is saved/restored inside the statement (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+
+template <typename T, int BM, int BN, int WM, int WN, bool RELU_IN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p) {
   constexpr int VEC = Elem<T>::VEC;
   constexpr int BK = 8 * VEC;  // elements per 128-byte chunk row
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int FM = WTM / 16, FN = WTN / 16;
   constexpr int A_ITERS = (BM + 31) / 32, B_ITERS = (BN + 31) / 32;
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_BYTES = BM * 128, B_BYTES = ((BN + 31) / 32) * 32 * 128, STAGE = A_BYTES + B_BYTES;
   static_assert(WM * WN == 4, "4 waves");
-  static_assert(WTM % 16 == 0 && WTN % 16 == 0, "fragment multiple");
+  static_assert(WTM % 16 == 0 && WTN % 16 == 0 && BM % 32 == 0, "fragment multiple");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int OHW = p.OH * p.OW;
   const int M = p.B * OHW;
@@ -84,71 +104,70 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
   const int tile_m = bid / nt, tile_n = bid - tile_m * nt;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  // ---- loader state: thread -> (row r0 + 32 i, 16-byte slot j) ----
-  const int j = tid & 7, r0 = tid >> 3;
-  int a_iy0[A_ITERS], a_ix0[A_ITERS];
-  long a_base[A_ITERS];
+  // ---- loader state.  One LDS-DMA instruction (global_load_lds_dwordx4) moves 1 KiB = 8 tile rows x
+  // 128 B per wave: lane L lands at LDS row (L>>3), physical 16-B slot (L&7).  The XOR swizzle is applied
+  // on the SOURCE side: lane L fetches logical slot j = (L&7) ^ ((row>>1)&7)  (rows advance by 32 per pass,
+  // so the swizzle term is the same for every pass of a thread). ----
+  const int r0 = tid >> 3;                       // tile row of pass 0
+  const int j = (tid & 7) ^ ((r0 >> 1) & 7);     // logical 16-byte slot within the 128-byte chunk row
+  const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
+  const char* zero = reinterpret_cast<const char*>(pf_zero_page);
+  const int ntaps = p.KH * p.KW;
+  const char* a_ptr[A_ITERS];
+  unsigned a_mask[A_ITERS];
 #pragma unroll
   for (int i = 0; i < A_ITERS; ++i) {
     const int m = m0 + r0 + 32 * i;
-    if (m < M && (r0 + 32 * i) < BM) {
+    a_mask[i] = 0u;
+    a_ptr[i] = zero;
+    if (m < M) {
       const int b = m / OHW, rem = m - b * OHW;
       const int oy = rem / p.OW, ox = rem - oy * p.OW;
-      a_iy0[i] = oy * p.stride - p.pad;
-      a_ix0[i] = ox * p.stride - p.pad;
-      a_base[i] = (long)b * p.H * p.W * p.x_ld;
-    } else {
-      a_iy0[i] = -(1 << 28);
-      a_ix0[i] = 0;
-      a_base[i] = 0;
+      const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+      a_ptr[i] = reinterpret_cast<const char*>(xg + ((long)b * p.H * p.W + (long)iy0 * p.W + ix0) * p.x_ld);
+      unsigned mk = 0u;
+      for (int t = 0; t < ntaps; ++t) {
+        const int ky = t / p.KW, kx = t - ky * p.KW;
+        if ((unsigned)(iy0 + ky) < (unsigned)p.H && (unsigned)(ix0 + kx) < (unsigned)p.W) mk |= 1u << t;
+      }
+      a_mask[i] = mk;
     }
   }
+  const char* b_ptr[B_ITERS];
+#pragma unroll
+  for (int i = 0; i < B_ITERS; ++i) {
+    const int row = n0 + r0 + 32 * i;
+    b_ptr[i] = (row < p.w_rows) ? reinterpret_cast<const char*>(wg + (long)row * p.Kpad + j * VEC) : nullptr;
+  }
   const int cin_v = p.Cin / VEC;
-  const int ntaps = p.KH * p.KW;
   const int nk = (ntaps * cin_v + 7) / 8;
-  const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
-  const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
+  // this thread's K position: vector index kv = kc*8 + j  ->  (tap = (ky,kx), cv)
+  int tap = j / cin_v, cv = j - tap * cin_v;
+  int ky = tap / p.KW, kx = tap - ky * p.KW;
 
-  uint4 ra[A_ITERS], rb[B_ITERS];
-  auto gload = [&](int kc) {
-    const int kv = kc * 8 + j;
-    const int tap = kv / cin_v;
-    const int cv = kv - tap * cin_v;
-    const int ky = tap / p.KW, kx = tap - ky * p.KW;
-    const bool tap_ok = tap < ntaps;
+  const unsigned smem_base = lds_addr(smem);
+  auto issue = [&](int stage, int kc) {
+    const unsigned As = smem_base + stage * STAGE + wave * (8 * 128);
+    const unsigned Bs = As + A_BYTES;
+    const long koff = ((long)(ky * p.W + kx) * p.x_ld + cv * VEC) * (long)sizeof(T);
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
-      const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
-      const bool ok = tap_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) v = *reinterpret_cast<const uint4*>(xg + a_base[i] + ((long)iy * p.W + ix) * p.x_ld + cv * VEC);
-      ra[i] = v;
+      const bool ok = (a_mask[i] >> tap) & 1u;
+      const char* src = ok ? a_ptr[i] + koff : zero;
+      glds16(src, As + i * (32 * 128));
     }
 #pragma unroll
     for (int i = 0; i < B_ITERS; ++i) {
-      const int rr = r0 + 32 * i;
-      const int row = n0 + rr;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (rr < BN && row < p.w_rows) v = *reinterpret_cast<const uint4*>(wg + (long)row * p.Kpad + (long)kc * BK + j * VEC);
-      rb[i] = v;
+      const char* src = b_ptr[i] ? b_ptr[i] + (long)kc * (BK * (long)sizeof(T)) : zero;
+      glds16(src, Bs + i * (32 * 128));
     }
-  };
-  auto lstore = [&](int stage) {
-    char* As = smem + stage * STAGE;
-    char* Bs = As + A_BYTES;
-#pragma unroll
-    for (int i = 0; i < A_ITERS; ++i) {
-      const int rr = r0 + 32 * i;
-      if (rr < BM) {
-        uint4 v = ra[i];
-        if (p.relu_in) v = relu_vec<T>(v);
-        *reinterpret_cast<uint4*>(As + rr * 128 + ((j ^ ((rr >> 1) & 7)) << 4)) = v;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < B_ITERS; ++i) {
-      const int rr = r0 + 32 * i;
-      if (rr < BN) *reinterpret_cast<uint4*>(Bs + rr * 128 + ((j ^ ((rr >> 1) & 7)) << 4)) = rb[i];
+    // advance this thread's K position by one chunk (8 vectors)
+    cv += 8;
+    while (cv >= cin_v) {
+      cv -= cin_v;
+      ++tap;
+      if (++kx == p.KW) { kx = 0; ++ky; }
     }
   };
 
@@ -164,12 +183,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
   const int a_row_off = (wm * WTM + fr) * 128;  // activations (pixels)
   const int b_row_off = (wn * WTN + fr) * 128;  // weights (channels)
 
-  gload(0);
-  lstore(0);
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int kc = 0; kc < nk; ++kc) {
-    const bool more = kc + 1 < nk;
-    if (more) gload(kc + 1);
+    if (kc + 1 < nk) issue((kc + 1) & 1, kc + 1);   // next chunk lands while this one is multiplied
     const char* As = smem + (kc & 1) * STAGE;
     const char* Bs = As + A_BYTES;
 #pragma unroll
@@ -179,12 +197,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
 #pragma unroll
       for (int fn = 0; fn < FN; ++fn) wf[fn] = *reinterpret_cast<const uint4*>(Bs + b_row_off + fn * 16 * 128 + slot);
 #pragma unroll
-      for (int fm = 0; fm < FM; ++fm) xf[fm] = *reinterpret_cast<const uint4*>(As + a_row_off + fm * 16 * 128 + slot);
+      for (int fm = 0; fm < FM; ++fm) {
+        xf[fm] = *reinterpret_cast<const uint4*>(As + a_row_off + fm * 16 * 128 + slot);
+        if constexpr (RELU_IN) xf[fm] = relu_vec<T>(xf[fm]);
+      }
       if constexpr (sizeof(T) == 2) mma_half_bf16<FM, FN>(wf, xf, acc);
       else mma_half_f32<FM, FN>(wf, xf, acc);
     }
-    if (more) lstore((kc + 1) & 1);
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk kc+1 has landed (this wave's pieces) ...
+    __syncthreads();                                    // ... for every wave; and stage kc&1 is free again
   }
 
   // ---- epilogue: bias -> act -> scale -> residual(s) -> store 4 consecutive channels ----
@@ -252,11 +273,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
 
 thread_local char g_err[256] = {0};
 
-template <typename T, int BM, int BN, int WM, int WN>
-int launch_cfg(const pf_conv_params& p, hipStream_t st) {
-  constexpr int smem = 2 * (BM + BN) * 128;
+template <typename T, int BM, int BN, int WM, int WN, bool RELU_IN>
+int launch_cfg2(const pf_conv_params& p, hipStream_t st) {
+  constexpr int smem = 2 * (BM + ((BN + 31) / 32) * 32) * 128;
   static bool attr_set = false;
-  auto kern = conv_igemm_kernel<T, BM, BN, WM, WN>;
+  auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, RELU_IN>;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
@@ -265,6 +286,11 @@ int launch_cfg(const pf_conv_params& p, hipStream_t st) {
   const long mt = (M + BM - 1) / BM, nt = (p.Cout + BN - 1) / BN;
   hipLaunchKernelGGL(kern, dim3((unsigned)(mt * nt)), dim3(256), smem, st, p);
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_LAUNCH;
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+int launch_cfg(const pf_conv_params& p, hipStream_t st) {
+  return p.relu_in ? launch_cfg2<T, BM, BN, WM, WN, true>(p, st) : launch_cfg2<T, BM, BN, WM, WN, false>(p, st);
 }
 
 template <typename T>
@@ -303,6 +329,7 @@ int validate(const pf_conv_params* p) {
   else if (p->w_rows < p->Cout) e = "w_rows < Cout";
   else if (p->shuffle > 1 && (p->Cout % (p->shuffle * p->shuffle) || (p->Cout / (p->shuffle * p->shuffle)) % 4)) e = "shuffle: Cout/(s*s) must be a multiple of 4";
   else if (p->shuffle > 1 && (p->KH != 1 || p->KW != 1 || p->res || p->res2)) e = "shuffle only for 1x1 without residual";
+  else if (p->KH * p->KW > 16) e = "at most 16 filter taps";
   else if ((long)p->B * p->OH * p->OW <= 0) e = "empty output";
   else if ((long)p->B * p->OH * p->OW >= (1L << 31)) e = "too many output pixels";
   if (e) { snprintf(g_err, sizeof(g_err), "pf_conv: %s", e); return PF_ERR_ARG; }

@@ -271,6 +271,233 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// "big" bf16 variant for the layers that carry the FLOPs (Cout >= 96, many pixels):
+// 512 threads = 8 waves (4 along pixels x 2 along channels), block tile 256 pixels x 128 channels, per-wave
+// 64x64 from 2x2 v_mfma_f32_32x32x16_bf16 fragments, K chunks of 64 through a THREE-deep LDS-DMA ring
+// (3 x 48 KiB = 144 KiB, one block per CU, two waves per SIMD).  Chunk k+2 is issued before chunk k is
+// multiplied and the per-chunk wait is a COUNTED s_waitcnt vmcnt(6) (= the 6 DMA instructions of the newest
+// chunk stay in flight across the barrier), so HBM/L2 latency is covered by two chunks of MFMA work.
+// Same LDS image / source-side swizzle / zero-page halo as conv_igemm_kernel.
+// 32x32x16 operand layout: lane l holds row (l&31), k = (l>>5)*8..+7 of a 16-deep step -> 16-byte slot
+// 2t + (l>>5) of the 128-byte row; D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+// -------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <bool RELU_IN>
+__global__ __launch_bounds__(512) void conv_igemm_big_kernel(const pf_conv_params p) {
+  using T = bf16_t;
+  constexpr int VEC = 8, BK = 64;
+  constexpr int BM = 256, BN = 128, NST = 3;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_ITERS = BM / 64, B_ITERS = BN / 64;  // 512 threads = 64 rows x 8 slots per pass
+  constexpr int NDMA = A_ITERS + B_ITERS;              // DMA instructions per wave per chunk (6)
+  static_assert(NDMA == 6, "vmcnt immediate below assumes 6");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int OHW = p.OH * p.OW;
+  const int M = p.B * OHW;
+  const int nt = (p.Cout + BN - 1) / BN;
+  const int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int tile_m = bid / nt, tile_n = bid - tile_m * nt;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int r0 = tid >> 3;                       // 0..63
+  const int j = (tid & 7) ^ ((r0 >> 1) & 7);     // logical slot fetched by this lane (source-side swizzle)
+  const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
+  const char* zero = reinterpret_cast<const char*>(pf_zero_page);
+  const int ntaps = p.KH * p.KW;
+  const char* a_ptr[A_ITERS];
+  unsigned a_mask[A_ITERS];
+#pragma unroll
+  for (int i = 0; i < A_ITERS; ++i) {
+    const int m = m0 + r0 + 64 * i;
+    a_mask[i] = 0u;
+    a_ptr[i] = zero;
+    if (m < M) {
+      const int b = m / OHW, rem = m - b * OHW;
+      const int oy = rem / p.OW, ox = rem - oy * p.OW;
+      const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+      a_ptr[i] = reinterpret_cast<const char*>(xg + ((long)b * p.H * p.W + (long)iy0 * p.W + ix0) * p.x_ld);
+      unsigned mk = 0u;
+      for (int t = 0; t < ntaps; ++t) {
+        const int ky = t / p.KW, kx = t - ky * p.KW;
+        if ((unsigned)(iy0 + ky) < (unsigned)p.H && (unsigned)(ix0 + kx) < (unsigned)p.W) mk |= 1u << t;
+      }
+      a_mask[i] = mk;
+    }
+  }
+  const char* b_ptr[B_ITERS];
+#pragma unroll
+  for (int i = 0; i < B_ITERS; ++i) {
+    const int row = n0 + r0 + 64 * i;
+    b_ptr[i] = (row < p.w_rows) ? reinterpret_cast<const char*>(wg + (long)row * p.Kpad + j * VEC) : nullptr;
+  }
+  const int cin_v = p.Cin / VEC;
+  const int nk = (ntaps * cin_v + 7) / 8;
+  int tap = j / cin_v, cv = j - tap * cin_v;
+  int ky = tap / p.KW, kx = tap - ky * p.KW;
+
+  const unsigned smem_base = lds_addr(smem);
+  auto issue = [&](int stage, int kc) {
+    const unsigned As = smem_base + stage * STAGE + wave * (8 * 128);
+    const unsigned Bs = As + A_BYTES;
+    const long koff = ((long)(ky * p.W + kx) * p.x_ld + cv * VEC) * (long)sizeof(T);
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      const bool ok = (a_mask[i] >> tap) & 1u;
+      const char* src = ok ? a_ptr[i] + koff : zero;
+      glds16(src, As + i * (64 * 128));
+    }
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i) {
+      const char* src = b_ptr[i] ? b_ptr[i] + (long)kc * (BK * (long)sizeof(T)) : zero;
+      glds16(src, Bs + i * (64 * 128));
+    }
+    cv += 8;
+    while (cv >= cin_v) {
+      cv -= cin_v;
+      ++tap;
+      if (++kx == p.KW) { kx = 0; ++ky; }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int fn = 0; fn < 2; ++fn)
+#pragma unroll
+    for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[fn][fm][e] = 0.f;
+
+  const int fr = lane & 31, fh = lane >> 5;
+  const int swz = (fr >> 1) & 7;
+  const int a_row_off = (wm * 64 + fr) * 128;  // activations (pixels)
+  const int b_row_off = (wn * 64 + fr) * 128;  // weights (channels)
+
+  issue(0, 0);
+  if (nk > 1) {
+    issue(1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  int st = 0;       // ring stage of chunk kc
+  for (int kc = 0; kc < nk; ++kc) {
+    const bool more2 = kc + 2 < nk;
+    if (more2) issue(st >= 1 ? st - 1 : 2, kc + 2);   // (st + 2) % 3 : the stage consumed in iteration kc-1
+    const char* As = smem + st * STAGE;
+    const char* Bs = As + A_BYTES;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int slot = (((t << 1) | fh) ^ swz) << 4;
+      uint4 wf[2], xf[2];
+#pragma unroll
+      for (int fn = 0; fn < 2; ++fn) wf[fn] = *reinterpret_cast<const uint4*>(Bs + b_row_off + fn * 32 * 128 + slot);
+#pragma unroll
+      for (int fm = 0; fm < 2; ++fm) {
+        xf[fm] = *reinterpret_cast<const uint4*>(As + a_row_off + fm * 32 * 128 + slot);
+        if constexpr (RELU_IN) xf[fm] = relu_vec<T>(xf[fm]);
+      }
+#pragma unroll
+      for (int fn = 0; fn < 2; ++fn)
+#pragma unroll
+        for (int fm = 0; fm < 2; ++fm)
+          acc[fn][fm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[fn]),
+                                                                __builtin_bit_cast(bf16x8, xf[fm]), acc[fn][fm], 0, 0, 0);
+    }
+    if (more2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // chunk kc+1 landed, kc+2 stays in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    st = st == 2 ? 0 : st + 1;
+  }
+
+  // ---- epilogue (same fused form as conv_igemm_kernel) ----
+  const int s = p.shuffle > 1 ? p.shuffle : 1;
+  const int cout_t = p.Cout / (s * s);
+#pragma unroll
+  for (int fm = 0; fm < 2; ++fm) {
+    const int m = m0 + wm * 64 + fm * 32 + fr;
+    if (m >= M) continue;
+    int b = 0, oy = 0, ox = 0;
+    if (s > 1) {
+      b = m / OHW;
+      const int rem = m - b * OHW;
+      oy = rem / p.OW;
+      ox = rem - oy * p.OW;
+    }
+#pragma unroll
+    for (int fn = 0; fn < 2; ++fn) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn * 64 + fn * 32 + 8 * q + 4 * fh;
+        if (n >= p.Cout) continue;
+        int co = n;
+        long opix = m;
+        if (s > 1) {
+          const int qq = n / cout_t;
+          co = n - qq * cout_t;
+          const int dy = qq / s, dx = qq - dy * s;
+          opix = ((long)b * (p.OH * s) + (oy * s + dy)) * (p.OW * s) + (ox * s + dx);
+        }
+        float v[4] = {acc[fn][fm][4 * q], acc[fn][fm][4 * q + 1], acc[fn][fm][4 * q + 2], acc[fn][fm][4 * q + 3]};
+        if (p.bias) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += p.bias[co + r];
+        }
+        if (p.act == PF_ACT_RELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        } else if (p.act == PF_ACT_GELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+        } else if (p.act == PF_ACT_SOFTPLUS) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = softplus20(v[r]);
+        }
+        if (p.scale) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= p.scale[co + r];
+        }
+        if (p.res) {
+          float t4[4];
+          load4(reinterpret_cast<const T*>(p.res) + opix * p.res_ld + co, t4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += t4[r];
+        }
+        if (p.res2) {
+          float t4[4];
+          load4(reinterpret_cast<const T*>(p.res2) + opix * p.res2_ld + co, t4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += t4[r];
+        }
+        if (p.out_f32) store4(reinterpret_cast<float*>(p.y) + opix * p.y_ld + co, v[0], v[1], v[2], v[3]);
+        else store4(reinterpret_cast<T*>(p.y) + opix * p.y_ld + co, v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+template <bool RELU_IN>
+int launch_big(const pf_conv_params& p, hipStream_t st) {
+  constexpr int smem = 3 * (256 + 128) * 128;
+  static bool attr_set = false;
+  auto kern = conv_igemm_big_kernel<RELU_IN>;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  const long M = (long)p.B * p.OH * p.OW;
+  const long mt = (M + 255) / 256, nt = (p.Cout + 127) / 128;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(mt * nt)), dim3(512), smem, st, p);
+  return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_LAUNCH;
+}
+
 thread_local char g_err[256] = {0};
 
 template <typename T, int BM, int BN, int WM, int WN, bool RELU_IN>
@@ -293,8 +520,19 @@ int launch_cfg(const pf_conv_params& p, hipStream_t st) {
   return p.relu_in ? launch_cfg2<T, BM, BN, WM, WN, true>(p, st) : launch_cfg2<T, BM, BN, WM, WN, false>(p, st);
 }
 
+int g_force_small = -1;   // PF_IGEMM_SMALL=1 forces the 4-wave kernel everywhere (A/B measurements)
+
 template <typename T>
 int dispatch(const pf_conv_params& p, hipStream_t st) {
+  if (g_force_small < 0) {
+    const char* e = getenv("PF_IGEMM_SMALL");
+    g_force_small = (e && e[0] == '1') ? 1 : 0;
+  }
+  if constexpr (sizeof(T) == 2) {
+    const long M = (long)p.B * p.OH * p.OW;
+    if (!g_force_small && p.Cout >= 96 && M >= 2048)
+      return p.relu_in ? launch_big<true>(p, st) : launch_big<false>(p, st);
+  }
   // pick the channel tile minimising padded work / tile efficiency
   const int cand[5] = {128, 96, 64, 32, 16};
   const float eff[5] = {1.0f, 0.97f, 0.9f, 0.8f, 0.6f};

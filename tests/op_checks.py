@@ -111,6 +111,45 @@ def conv3x3_nobias_48(dt):
     return _conv_case(dt, 1, 32, 44, 48, 64, 3, pad=1, bias=False)
 
 
+# ---- shapes that take the 8-wave 256x128 "big" bf16 kernel (Cout >= 96 and >= 2048 output pixels) ----
+def conv_big_3x3_rcu(dt):
+    return _conv_case(dt, 2, 40, 52, 128, 128, 3, pad=1, relu_in=True, res=True, res2=True, seed=11)
+
+
+def conv_big_3x3_n544_views(dt):
+    return _conv_case(dt, 1, 48, 50, 544, 544, 3, pad=1, act="relu", x_extra=32, y_extra=32, seed=12)
+
+
+def conv_big_3x3_n160(dt):
+    return _conv_case(dt, 3, 30, 41, 160, 160, 3, pad=1, act="relu", seed=13)
+
+
+def conv_big_stride2(dt):
+    return _conv_case(dt, 1, 96, 100, 96, 192, 3, stride=2, pad=1, seed=14)
+
+
+def conv_big_gemm_scale_inplace(dt):
+    return _conv_case(dt, 1, 1, 2 * 1037, 1536, 384, 1, scale=True, res=True, inplace=True, seed=15)
+
+
+def conv_big_gemm_gelu_k1024(dt):
+    return _conv_case(dt, 1, 1, 3 * 1037, 1024, 4096, 1, act="gelu", seed=16)
+
+
+def conv_big_transpose(dt):
+    w = torch.randn(96, 96, 2, 2, generator=torch.Generator().manual_seed(3)) / 96 ** 0.5
+    b = torch.randn(96, generator=torch.Generator().manual_seed(4))
+    pw = pk.pack_conv_transpose(w, b, dtype=dt).to(DEV)
+    x = _rand((2, 40, 52, 96), dt, 7)
+    ys = []
+    for o in (hip(), ref_ops):
+        y = torch.zeros((2, 80, 104, 96), dtype=dt, device=DEV)
+        o.conv(x, pw, y)
+        ys.append(y)
+    torch.cuda.synchronize()
+    return _err(ys[0], ys[1]), _tol(dt), "convT s2 big"
+
+
 def conv_transpose(dt):
     errs = []
     for s, cin in ((4, 48), (2, 96)):
@@ -333,6 +372,10 @@ CHECKS = {
     "conv3x3_rcu": conv3x3_rcu, "conv3x3_stride2": conv3x3_stride2, "conv3x3_small_cin": conv3x3_small_cin,
     "conv3x3_n160_views": conv3x3_n160_views, "conv3x3_n544": conv3x3_n544, "conv1x1_cout1_f32out": conv1x1_cout1_f32out,
     "conv1x1_cout80": conv1x1_cout80, "conv1x1_cout16": conv1x1_cout16, "conv3x3_nobias_48": conv3x3_nobias_48,
+    "conv_big_3x3_rcu": conv_big_3x3_rcu, "conv_big_3x3_n544_views": conv_big_3x3_n544_views,
+    "conv_big_3x3_n160": conv_big_3x3_n160, "conv_big_stride2": conv_big_stride2,
+    "conv_big_gemm_scale_inplace": conv_big_gemm_scale_inplace, "conv_big_gemm_gelu_k1024": conv_big_gemm_gelu_k1024,
+    "conv_big_transpose": conv_big_transpose,
     "conv_transpose": conv_transpose, "patch_embed_tokens": patch_embed_tokens, "layernorm": layernorm,
     "vit_attention": vit_attention, "swin_ops": swin_ops, "resize_ops": resize_ops, "roi_ops": roi_ops,
     "misc_ops": misc_ops, "bins_ops": bins_ops, "stitch_ops": stitch_ops,

@@ -49,8 +49,13 @@ def main():
     ap.add_argument("--process-num", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true", help="only time the dominant kernel (kernel tuning aid)")
     args = ap.parse_args()
 
+    if args.roofline_only:
+        torch.cuda.set_device(0)
+        print(json.dumps(roofline(args.dtype, torch.device("cuda", 0))), flush=True)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

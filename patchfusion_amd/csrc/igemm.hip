@@ -63,6 +63,10 @@ __device__ __forceinline__ void mma_half_f32(const uint4 (&wf)[FN], const uint4 
       }
 }
 
+// Measurement aid (PF_IGEMM_ABLATE=1: skip the DMA after the prologue; =2: skip ds_read+MFMA). Results are
+// wrong by construction in these modes; they are only used with pf_conv_timed to locate the bottleneck.
+__device__ int pf_ablate = 0;
+
 // 256 bytes of zeros: source of every out-of-image / out-of-range 16-byte vector (conv padding, M/N tails)
 __device__ __attribute__((aligned(256))) unsigned int pf_zero_page[64];
 
@@ -183,13 +187,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
   const int a_row_off = (wm * WTM + fr) * 128;  // activations (pixels)
   const int b_row_off = (wn * WTN + fr) * 128;  // weights (channels)
 
+  const int ablate = pf_ablate;
   issue(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int kc = 0; kc < nk; ++kc) {
-    if (kc + 1 < nk) issue((kc + 1) & 1, kc + 1);   // next chunk lands while this one is multiplied
+    if (kc + 1 < nk && ablate != 1) issue((kc + 1) & 1, kc + 1);   // next chunk lands while this one is multiplied
     const char* As = smem + (kc & 1) * STAGE;
     const char* Bs = As + A_BYTES;
+    if (ablate != 2)
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int slot = (((s << 2) | fg) ^ swz) << 4;
@@ -379,6 +385,7 @@ __global__ __launch_bounds__(512) void conv_igemm_big_kernel(const pf_conv_param
   const int a_row_off = (wm * 64 + fr) * 128;  // activations (pixels)
   const int b_row_off = (wn * 64 + fr) * 128;  // weights (channels)
 
+  const int ablate = pf_ablate;
   issue(0, 0);
   if (nk > 1) {
     issue(1, 1);
@@ -389,10 +396,11 @@ __global__ __launch_bounds__(512) void conv_igemm_big_kernel(const pf_conv_param
   __syncthreads();
   int st = 0;       // ring stage of chunk kc
   for (int kc = 0; kc < nk; ++kc) {
-    const bool more2 = kc + 2 < nk;
+    const bool more2 = kc + 2 < nk && ablate != 1;
     if (more2) issue(st >= 1 ? st - 1 : 2, kc + 2);   // (st + 2) % 3 : the stage consumed in iteration kc-1
     const char* As = smem + st * STAGE;
     const char* Bs = As + A_BYTES;
+    if (ablate != 2)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int slot = (((t << 1) | fh) ^ swz) << 4;
@@ -498,6 +506,242 @@ int launch_big(const pf_conv_params& p, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_LAUNCH;
 }
 
+// -------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution with TAP REUSE (the FLOP-dominant class: fusion U-Net, DPT RCUs):
+// the implicit-GEMM kernels above re-fetch every input pixel once per filter tap (9x) through the
+// per-CU global->LDS path, which ablation shows to be as expensive as the MFMA work itself.  Here a block
+// owns a 16x32-pixel output tile of one image; per 32-channel chunk the 18x34 input HALO tile is brought
+// into LDS ONCE (double buffered) and all nine taps are multiplied out of it, only the 8-12 KiB weight
+// tile changes per tap (3-deep ring).  8 waves = 4 (pixel rows) x 2 (channels); wave tile 128 px x 32*FN
+// channels from 4 x FN v_mfma_f32_32x32x16_bf16 fragments (FN = 2 -> BN 128, FN = 3 -> BN 192).
+// LDS rows are 64 B (32 bf16 channels); 16-byte slot swizzle phys = slot ^ ((row>>2)&3) is conflict free for
+// any 32-row fragment start (halo fragments start at arbitrary rows) -- DESIGN.md section 4.
+// Counted waits: every step a wave issues [<=1 halo piece of the NEXT chunk, the weight tile of step+2]
+// and then waits vmcnt(#issued this step) => the weight tile of step+1 (and older halo pieces) have landed.
+// -------------------------------------------------------------------------------------------------
+template <int FN, bool RELU_IN>
+__global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params p) {
+  using T = bf16_t;
+  constexpr int TH = 16, TW = 32, HW_ = TW + 2, HROWS = (TH + 2) * HW_;   // 612 halo pixels
+  constexpr int A_PIECES = (HROWS + 15) / 16;                               // 39 DMA pieces of 16 rows
+  constexpr int A_BUF = 40960;                                              // >= 39*16*64
+  constexpr int BN = 64 * FN, W_TILE = BN * 64, W_PIECES = BN / 16;         // weight tile: BN rows x 64 B
+  constexpr int W_PER_WAVE = (W_PIECES + 7) / 8;                            // 1 (BN 128) or 2 (BN 192: 12 pieces)
+  constexpr int LDS_W0 = 2 * A_BUF;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+  const int nt = (p.Cout + BN - 1) / BN;
+  const int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int tile_m = bid / nt, tile_n = bid - tile_m * nt;
+  const int b = tile_m / (tiles_x * tiles_y);
+  const int trem = tile_m - b * tiles_x * tiles_y;
+  const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * TW;
+  const int n0 = tile_n * BN;
+
+  const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
+  const char* zero = reinterpret_cast<const char*>(pf_zero_page);
+
+  // ---- DMA sources.  A piece = 16 halo rows x 64 B: lane L -> row 16*piece + (L>>2), physical slot L&3,
+  // fetching logical slot (L&3) ^ ((row>>2)&3).  Wave w owns pieces w, w+8, ..., (<39). ----
+  const char* a_src[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int piece = wave + 8 * i;
+    const int row = piece * 16 + (lane >> 2);
+    const int jl = (lane & 3) ^ ((row >> 2) & 3);
+    const int hy = row / HW_, hx = row - hy * HW_;
+    const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+    const bool ok = piece < A_PIECES && row < HROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    a_src[i] = ok ? reinterpret_cast<const char*>(xg + (((long)b * p.H + iy) * p.W + ix) * p.x_ld + jl * 8) : nullptr;
+  }
+  const char* w_src[W_PER_WAVE];
+#pragma unroll
+  for (int i = 0; i < W_PER_WAVE; ++i) {
+    const int piece = wave + 8 * i;
+    const int row = piece * 16 + (lane >> 2);
+    const int jl = (lane & 3) ^ ((row >> 2) & 3);
+    const bool ok = piece < W_PIECES && (n0 + row) < p.w_rows;
+    w_src[i] = ok ? reinterpret_cast<const char*>(wg + (long)(n0 + row) * p.Kpad + jl * 8) : nullptr;
+  }
+  const int nchunks = p.Cin / 32;
+  const int G = nchunks * 9;
+  const unsigned smem_base = lds_addr(smem);
+
+  auto issue_a = [&](int i, int chunk) {   // piece i of this wave for channel chunk `chunk`
+    const char* src = a_src[i] ? a_src[i] + (long)chunk * 64 : zero;
+    glds16(src, smem_base + (chunk & 1) * A_BUF + (wave + 8 * i) * 1024);
+  };
+  auto issue_w = [&](int g) {              // weight tile of global step g = chunk*9 + tap -> ring slot g%3
+    const int chunk = g / 9, tap = g - chunk * 9;
+    const long off = ((long)tap * p.Cin + chunk * 32) * 2;
+    const unsigned dst = smem_base + LDS_W0 + (g % 3) * W_TILE;
+#pragma unroll
+    for (int i = 0; i < W_PER_WAVE; ++i) {
+      if (wave + 8 * i < W_PIECES) {
+        const char* src = w_src[i] ? w_src[i] + off : zero;
+        glds16(src, dst + (wave + 8 * i) * 1024);
+      }
+    }
+  };
+  const int n_wdma = (wave + 8 < W_PIECES) ? 2 : (wave < W_PIECES ? 1 : 0);   // weight DMAs this wave issues per step
+
+  f32x16 acc[FN][4];
+#pragma unroll
+  for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+    for (int fm = 0; fm < 4; ++fm)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[fn][fm][e] = 0.f;
+
+  const int fr = lane & 31, fh = lane >> 5;
+  int arow_base[4];
+#pragma unroll
+  for (int fm = 0; fm < 4; ++fm) arow_base[fm] = (4 * wm + fm) * HW_ + fr;
+  int w_off[FN];   // byte offset of this lane's weight row inside a weight tile, swizzle term folded per k-step below
+  int w_swz[FN];
+#pragma unroll
+  for (int fn = 0; fn < FN; ++fn) {
+    const int row = wn * (32 * FN) + fn * 32 + fr;
+    w_off[fn] = row * 64;
+    w_swz[fn] = (row >> 2) & 3;
+  }
+
+  // ---- prologue: whole halo of chunk 0, weight tiles of steps 0 and 1 ----
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+    if (wave + 8 * i < A_PIECES) issue_a(i, 0);
+  issue_w(0);
+  if (G > 1) issue_w(1);
+  if (G > 1) {
+    if (n_wdma == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (n_wdma == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+
+  int chunk = 0, tap = 0, ky = 0, kx = 0;
+  for (int g = 0; g < G; ++g) {
+    // ---- issue: one halo piece of the next chunk (steps 0..4), then the weight tile of step g+2 ----
+    int issued = 0;
+    if (tap < 5 && chunk + 1 < nchunks && wave + 8 * tap < A_PIECES) {
+      switch (tap) {   // a_src index must be a compile-time constant (registers, not scratch)
+        case 0: issue_a(0, chunk + 1); break;
+        case 1: issue_a(1, chunk + 1); break;
+        case 2: issue_a(2, chunk + 1); break;
+        case 3: issue_a(3, chunk + 1); break;
+        default: issue_a(4, chunk + 1); break;
+      }
+      issued += 1;
+    }
+    if (g + 2 < G) {
+      issue_w(g + 2);
+      issued += n_wdma;
+    }
+    // ---- multiply tap (ky,kx) of this chunk ----
+    const char* Ab = smem + (chunk & 1) * A_BUF;
+    const char* Wb = smem + LDS_W0 + (g % 3) * W_TILE;
+    const int tap_off = ky * HW_ + kx;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int slot = (t << 1) | fh;
+      uint4 wf[FN], xf[4];
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn) wf[fn] = *reinterpret_cast<const uint4*>(Wb + w_off[fn] + ((slot ^ w_swz[fn]) << 4));
+#pragma unroll
+      for (int fm = 0; fm < 4; ++fm) {
+        const int row = arow_base[fm] + tap_off;
+        xf[fm] = *reinterpret_cast<const uint4*>(Ab + row * 64 + ((slot ^ ((row >> 2) & 3)) << 4));
+        if constexpr (RELU_IN) xf[fm] = relu_vec<T>(xf[fm]);
+      }
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+        for (int fm = 0; fm < 4; ++fm)
+          acc[fn][fm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[fn]),
+                                                                __builtin_bit_cast(bf16x8, xf[fm]), acc[fn][fm], 0, 0, 0);
+    }
+    // ---- the weight tile of step g+1 (issued last in step g-1) and everything older have landed ----
+    if (issued == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (issued == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if (issued == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    __syncthreads();
+    if (++kx == 3) { kx = 0; ++ky; }
+    if (++tap == 9) { tap = 0; ky = 0; ++chunk; }
+  }
+
+  // ---- epilogue ----
+#pragma unroll
+  for (int fm = 0; fm < 4; ++fm) {
+    const int oy = ty0 + 4 * wm + fm, ox = tx0 + fr;
+    if (oy >= p.H || ox >= p.W) continue;
+    const long opix = ((long)b * p.H + oy) * p.W + ox;
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = n0 + wn * (32 * FN) + fn * 32 + 8 * q + 4 * fh;
+        if (co >= p.Cout) continue;
+        float v[4] = {acc[fn][fm][4 * q], acc[fn][fm][4 * q + 1], acc[fn][fm][4 * q + 2], acc[fn][fm][4 * q + 3]};
+        if (p.bias) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += p.bias[co + r];
+        }
+        if (p.act == PF_ACT_RELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        } else if (p.act == PF_ACT_GELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+        } else if (p.act == PF_ACT_SOFTPLUS) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = softplus20(v[r]);
+        }
+        if (p.scale) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= p.scale[co + r];
+        }
+        if (p.res) {
+          float t4[4];
+          load4(reinterpret_cast<const T*>(p.res) + opix * p.res_ld + co, t4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += t4[r];
+        }
+        if (p.res2) {
+          float t4[4];
+          load4(reinterpret_cast<const T*>(p.res2) + opix * p.res2_ld + co, t4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += t4[r];
+        }
+        if (p.out_f32) store4(reinterpret_cast<float*>(p.y) + opix * p.y_ld + co, v[0], v[1], v[2], v[3]);
+        else store4(reinterpret_cast<T*>(p.y) + opix * p.y_ld + co, v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+template <int FN, bool RELU_IN>
+int launch_halo(const pf_conv_params& p, hipStream_t st) {
+  constexpr int smem = 2 * 40960 + 3 * (64 * FN) * 64;
+  static bool attr_set = false;
+  auto kern = conv3x3_halo_kernel<FN, RELU_IN>;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  const long tiles = (long)p.B * ((p.H + 15) / 16) * ((p.W + 31) / 32);
+  const long nt = (p.Cout + 64 * FN - 1) / (64 * FN);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * nt)), dim3(512), smem, st, p);
+  return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_LAUNCH;
+}
+
 thread_local char g_err[256] = {0};
 
 template <typename T, int BM, int BN, int WM, int WN, bool RELU_IN>
@@ -526,11 +770,21 @@ template <typename T>
 int dispatch(const pf_conv_params& p, hipStream_t st) {
   if (g_force_small < 0) {
     const char* e = getenv("PF_IGEMM_SMALL");
-    g_force_small = (e && e[0] == '1') ? 1 : 0;
+    g_force_small = e ? atoi(e) : 0;   // 1: 4-wave kernel everywhere; 2: no halo kernel (big/small only)
+    const char* a = getenv("PF_IGEMM_ABLATE");
+    int av = a ? atoi(a) : 0;
+    hipMemcpyToSymbol(HIP_SYMBOL(pf_ablate), &av, sizeof(int));
   }
   if constexpr (sizeof(T) == 2) {
     const long M = (long)p.B * p.OH * p.OW;
-    if (!g_force_small && p.Cout >= 96 && M >= 2048)
+    if (g_force_small != 1 && g_force_small != 2 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.shuffle <= 1 &&
+        p.Cin % 32 == 0 && p.Cout >= 96 && p.H >= 16 && p.W >= 32 && M >= 2048) {
+      // channel tile: 192 when it wastes less than 128 (e.g. 544 -> 3x192 = 576 vs 5x128 = 640; 768 -> 4x192)
+      const int pad128 = (p.Cout + 127) / 128 * 128, pad192 = (p.Cout + 191) / 192 * 192;
+      if (pad192 <= pad128) return p.relu_in ? launch_halo<3, true>(p, st) : launch_halo<3, false>(p, st);
+      return p.relu_in ? launch_halo<2, true>(p, st) : launch_halo<2, false>(p, st);
+    }
+    if (g_force_small != 1 && p.Cout >= 96 && M >= 2048)
       return p.relu_in ? launch_big<true>(p, st) : launch_big<false>(p, st);
   }
   // pick the channel tile minimising padded work / tile efficiency

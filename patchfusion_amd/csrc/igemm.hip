@@ -516,17 +516,20 @@ int launch_big(const pf_conv_params& p, hipStream_t st) {
 // channels from 4 x FN v_mfma_f32_32x32x16_bf16 fragments (FN = 2 -> BN 128, FN = 3 -> BN 192).
 // LDS rows are 64 B (32 bf16 channels); 16-byte slot swizzle phys = slot ^ ((row>>2)&3) is conflict free for
 // any 32-row fragment start (halo fragments start at arbitrary rows) -- DESIGN.md section 4.
-// Counted waits: every step a wave issues [<=1 halo piece of the NEXT chunk, the weight tile of step+2]
-// and then waits vmcnt(#issued this step) => the weight tile of step+1 (and older halo pieces) have landed.
+// A step = one filter ROW (3 taps) of one chunk: its 3 x BN x 64 B weight tiles sit in a 2-deep ring; at the
+// start of step g every wave issues a third of the NEXT chunk's halo and the weights of step g+1, which have
+// the whole step (72 MFMAs per wave) to land before the single vmcnt(0)+barrier that ends it.
 // -------------------------------------------------------------------------------------------------
 template <int FN, bool RELU_IN>
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params p) {
   using T = bf16_t;
   constexpr int TH = 16, TW = 32, HW_ = TW + 2, HROWS = (TH + 2) * HW_;   // 612 halo pixels
   constexpr int A_PIECES = (HROWS + 15) / 16;                               // 39 DMA pieces of 16 rows
+  constexpr int A_PER_STEP = (A_PIECES + 2) / 3;                            // 13 pieces issued per step (3 steps / chunk)
   constexpr int A_BUF = 40960;                                              // >= 39*16*64
-  constexpr int BN = 64 * FN, W_TILE = BN * 64, W_PIECES = BN / 16;         // weight tile: BN rows x 64 B
-  constexpr int W_PER_WAVE = (W_PIECES + 7) / 8;                            // 1 (BN 128) or 2 (BN 192: 12 pieces)
+  constexpr int BN = 64 * FN, W_TILE = BN * 64, W_PIECES = BN / 16;         // per-tap weight tile: BN rows x 64 B
+  constexpr int W_STAGE = 3 * W_TILE, WQ = 3 * W_PIECES;                    // one filter ROW (3 taps) per step
+  constexpr int WQ_PER_WAVE = (WQ + 7) / 8;                                 // 3 (BN 128) or 5 (BN 192)
   constexpr int LDS_W0 = 2 * A_BUF;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -547,48 +550,63 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params 
   const char* zero = reinterpret_cast<const char*>(pf_zero_page);
 
   // ---- DMA sources.  A piece = 16 halo rows x 64 B: lane L -> row 16*piece + (L>>2), physical slot L&3,
-  // fetching logical slot (L&3) ^ ((row>>2)&3).  Wave w owns pieces w, w+8, ..., (<39). ----
-  const char* a_src[5];
+  // fetching logical slot (L&3) ^ ((row>>2)&3).  In step ky of a chunk, wave w issues pieces
+  // ky*13 + w and ky*13 + w + 8 of the NEXT chunk's halo (when < 13 within the step and < 39 overall). ----
+  unsigned a_src[3][2];   // byte offsets from p.x (tensors are < 4 GiB); ~0u = outside the image
+  const char* xbase = reinterpret_cast<const char*>(xg);
+  const char* wbase = reinterpret_cast<const char*>(wg);
 #pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const int piece = wave + 8 * i;
+  for (int st = 0; st < 3; ++st)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = wave + 8 * i;
+      const int piece = st * A_PER_STEP + q;
+      const int row = piece * 16 + (lane >> 2);
+      const int jl = (lane & 3) ^ ((row >> 2) & 3);
+      const int hy = row / HW_, hx = row - hy * HW_;
+      const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+      const bool ok = q < A_PER_STEP && piece < A_PIECES && row < HROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      a_src[st][i] = ok ? (unsigned)(((((long)b * p.H + iy) * p.W + ix) * p.x_ld + jl * 8) * 2) : ~0u;
+    }
+  // weight pieces of one step: q = kx*W_PIECES + piece16 ; wave w issues q = w, w+8, ...
+  unsigned w_src[WQ_PER_WAVE];   // byte offsets from p.w; ~0u = beyond the packed rows
+#pragma unroll
+  for (int i = 0; i < WQ_PER_WAVE; ++i) {
+    const int q = wave + 8 * i;
+    const int kxq = q / W_PIECES, piece = q - kxq * W_PIECES;
     const int row = piece * 16 + (lane >> 2);
     const int jl = (lane & 3) ^ ((row >> 2) & 3);
-    const int hy = row / HW_, hx = row - hy * HW_;
-    const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
-    const bool ok = piece < A_PIECES && row < HROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-    a_src[i] = ok ? reinterpret_cast<const char*>(xg + (((long)b * p.H + iy) * p.W + ix) * p.x_ld + jl * 8) : nullptr;
-  }
-  const char* w_src[W_PER_WAVE];
-#pragma unroll
-  for (int i = 0; i < W_PER_WAVE; ++i) {
-    const int piece = wave + 8 * i;
-    const int row = piece * 16 + (lane >> 2);
-    const int jl = (lane & 3) ^ ((row >> 2) & 3);
-    const bool ok = piece < W_PIECES && (n0 + row) < p.w_rows;
-    w_src[i] = ok ? reinterpret_cast<const char*>(wg + (long)(n0 + row) * p.Kpad + jl * 8) : nullptr;
+    const bool ok = q < WQ && (n0 + row) < p.w_rows;
+    w_src[i] = ok ? (unsigned)(((long)(n0 + row) * p.Kpad + (long)kxq * p.Cin + jl * 8) * 2) : ~0u;
   }
   const int nchunks = p.Cin / 32;
-  const int G = nchunks * 9;
+  const int G = nchunks * 3;                 // steps: (chunk, ky)
   const unsigned smem_base = lds_addr(smem);
 
-  auto issue_a = [&](int i, int chunk) {   // piece i of this wave for channel chunk `chunk`
-    const char* src = a_src[i] ? a_src[i] + (long)chunk * 64 : zero;
-    glds16(src, smem_base + (chunk & 1) * A_BUF + (wave + 8 * i) * 1024);
-  };
-  auto issue_w = [&](int g) {              // weight tile of global step g = chunk*9 + tap -> ring slot g%3
-    const int chunk = g / 9, tap = g - chunk * 9;
-    const long off = ((long)tap * p.Cin + chunk * 32) * 2;
-    const unsigned dst = smem_base + LDS_W0 + (g % 3) * W_TILE;
+  auto issue_a = [&](int st, int chunk) {    // this wave's halo pieces of step-slot st for channel chunk `chunk`
 #pragma unroll
-    for (int i = 0; i < W_PER_WAVE; ++i) {
-      if (wave + 8 * i < W_PIECES) {
-        const char* src = w_src[i] ? w_src[i] + off : zero;
-        glds16(src, dst + (wave + 8 * i) * 1024);
+    for (int i = 0; i < 2; ++i) {
+      const int q = wave + 8 * i;
+      if (q < A_PER_STEP && st * A_PER_STEP + q < A_PIECES) {
+        const unsigned off = st == 0 ? a_src[0][i] : (st == 1 ? a_src[1][i] : a_src[2][i]);
+        const char* src = off != ~0u ? xbase + off + (long)chunk * 64 : zero;
+        glds16(src, smem_base + (chunk & 1) * A_BUF + (st * A_PER_STEP + q) * 1024);
       }
     }
   };
-  const int n_wdma = (wave + 8 < W_PIECES) ? 2 : (wave < W_PIECES ? 1 : 0);   // weight DMAs this wave issues per step
+  auto issue_w = [&](int g) {                // weight row-tile of step g = chunk*3 + ky -> ring slot g&1
+    const int chunk = g / 3, kyy = g - chunk * 3;
+    const long off = ((long)(kyy * 3) * p.Cin + chunk * 32) * 2;
+    const unsigned dst = smem_base + LDS_W0 + (g & 1) * W_STAGE;
+#pragma unroll
+    for (int i = 0; i < WQ_PER_WAVE; ++i) {
+      const int q = wave + 8 * i;
+      if (q < WQ) {
+        const char* src = w_src[i] != ~0u ? wbase + w_src[i] + off : zero;
+        glds16(src, dst + q * 1024);
+      }
+    }
+  };
 
   f32x16 acc[FN][4];
 #pragma unroll
@@ -602,8 +620,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params 
   int arow_base[4];
 #pragma unroll
   for (int fm = 0; fm < 4; ++fm) arow_base[fm] = (4 * wm + fm) * HW_ + fr;
-  int w_off[FN];   // byte offset of this lane's weight row inside a weight tile, swizzle term folded per k-step below
-  int w_swz[FN];
+  int w_off[FN], w_swz[FN];
 #pragma unroll
   for (int fn = 0; fn < FN; ++fn) {
     const int row = wn * (32 * FN) + fn * 32 + fr;
@@ -611,70 +628,54 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params 
     w_swz[fn] = (row >> 2) & 3;
   }
 
-  // ---- prologue: whole halo of chunk 0, weight tiles of steps 0 and 1 ----
-#pragma unroll
-  for (int i = 0; i < 5; ++i)
-    if (wave + 8 * i < A_PIECES) issue_a(i, 0);
+  // ---- prologue: whole halo of chunk 0 and the weight rows of step 0 ----
+  issue_a(0, 0);
+  issue_a(1, 0);
+  issue_a(2, 0);
   issue_w(0);
-  if (G > 1) issue_w(1);
-  if (G > 1) {
-    if (n_wdma == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if (n_wdma == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  int chunk = 0, tap = 0, ky = 0, kx = 0;
+  int chunk = 0, ky = 0;
   for (int g = 0; g < G; ++g) {
-    // ---- issue: one halo piece of the next chunk (steps 0..4), then the weight tile of step g+2 ----
-    int issued = 0;
-    if (tap < 5 && chunk + 1 < nchunks && wave + 8 * tap < A_PIECES) {
-      switch (tap) {   // a_src index must be a compile-time constant (registers, not scratch)
-        case 0: issue_a(0, chunk + 1); break;
-        case 1: issue_a(1, chunk + 1); break;
-        case 2: issue_a(2, chunk + 1); break;
-        case 3: issue_a(3, chunk + 1); break;
-        default: issue_a(4, chunk + 1); break;
-      }
-      issued += 1;
+    // ---- issue: a third of the next chunk's halo, then the weight rows of step g+1 (other ring slot) ----
+    if (chunk + 1 < nchunks) {
+      if (ky == 0) issue_a(0, chunk + 1);
+      else if (ky == 1) issue_a(1, chunk + 1);
+      else issue_a(2, chunk + 1);
     }
-    if (g + 2 < G) {
-      issue_w(g + 2);
-      issued += n_wdma;
-    }
-    // ---- multiply tap (ky,kx) of this chunk ----
+    if (g + 1 < G) issue_w(g + 1);
+    // ---- multiply filter row ky (three taps) of this chunk ----
     const char* Ab = smem + (chunk & 1) * A_BUF;
-    const char* Wb = smem + LDS_W0 + (g % 3) * W_TILE;
-    const int tap_off = ky * HW_ + kx;
+    const char* Wb = smem + LDS_W0 + (g & 1) * W_STAGE;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int slot = (t << 1) | fh;
-      uint4 wf[FN], xf[4];
+    for (int kx = 0; kx < 3; ++kx) {
+      const int tap_off = ky * HW_ + kx;
 #pragma unroll
-      for (int fn = 0; fn < FN; ++fn) wf[fn] = *reinterpret_cast<const uint4*>(Wb + w_off[fn] + ((slot ^ w_swz[fn]) << 4));
+      for (int t = 0; t < 2; ++t) {
+        const int slot = (t << 1) | fh;
+        uint4 wf[FN], xf[4];
 #pragma unroll
-      for (int fm = 0; fm < 4; ++fm) {
-        const int row = arow_base[fm] + tap_off;
-        xf[fm] = *reinterpret_cast<const uint4*>(Ab + row * 64 + ((slot ^ ((row >> 2) & 3)) << 4));
-        if constexpr (RELU_IN) xf[fm] = relu_vec<T>(xf[fm]);
+        for (int fn = 0; fn < FN; ++fn)
+          wf[fn] = *reinterpret_cast<const uint4*>(Wb + kx * W_TILE + w_off[fn] + ((slot ^ w_swz[fn]) << 4));
+#pragma unroll
+        for (int fm = 0; fm < 4; ++fm) {
+          const int row = arow_base[fm] + tap_off;
+          xf[fm] = *reinterpret_cast<const uint4*>(Ab + row * 64 + ((slot ^ ((row >> 2) & 3)) << 4));
+          if constexpr (RELU_IN) xf[fm] = relu_vec<T>(xf[fm]);
+        }
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+          for (int fm = 0; fm < 4; ++fm)
+            acc[fn][fm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[fn]),
+                                                                  __builtin_bit_cast(bf16x8, xf[fm]), acc[fn][fm], 0, 0, 0);
       }
-#pragma unroll
-      for (int fn = 0; fn < FN; ++fn)
-#pragma unroll
-        for (int fm = 0; fm < 4; ++fm)
-          acc[fn][fm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[fn]),
-                                                                __builtin_bit_cast(bf16x8, xf[fm]), acc[fn][fm], 0, 0, 0);
     }
-    // ---- the weight tile of step g+1 (issued last in step g-1) and everything older have landed ----
-    if (issued == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (issued == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else if (issued == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    // ---- everything issued this step (weights of g+1, halo pieces) has a whole step of MFMA to land ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (++kx == 3) { kx = 0; ++ky; }
-    if (++tap == 9) { tap = 0; ky = 0; ++chunk; }
+    if (++ky == 3) { ky = 0; ++chunk; }
   }
 
   // ---- epilogue ----
@@ -729,7 +730,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params 
 
 template <int FN, bool RELU_IN>
 int launch_halo(const pf_conv_params& p, hipStream_t st) {
-  constexpr int smem = 2 * 40960 + 3 * (64 * FN) * 64;
+  constexpr int smem = 2 * 40960 + 2 * 3 * (64 * FN) * 64;
   static bool attr_set = false;
   auto kern = conv3x3_halo_kernel<FN, RELU_IN>;
   if (!attr_set) {

@@ -50,8 +50,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true", help="only time the dominant kernel (kernel tuning aid)")
+    ap.add_argument("--gemm-sweep", action="store_true", help="time the ViT-L linear layers / other shapes (kernel tuning aid)")
     args = ap.parse_args()
 
+    if args.gemm_sweep:
+        torch.cuda.set_device(0)
+        gemm_sweep(args.dtype, torch.device("cuda", 0))
+        return
     if args.roofline_only:
         torch.cuda.set_device(0)
         print(json.dumps(roofline(args.dtype, torch.device("cuda", 0))), flush=True)
@@ -130,6 +135,30 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def gemm_sweep(dtype, dev):
+    from patchfusion_amd import packing as pk
+    from patchfusion_amd.hip_ops import ops
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    shapes = [("qkv", 8296, 1024, 3072, 1), ("proj", 8296, 1024, 1024, 1), ("fc1", 8296, 1024, 4096, 1), ("fc2", 8296, 4096, 1024, 1),
+              ("up4_1", 8 * 224 * 296, 768, 768, 3), ("up4_2", 8 * 224 * 296, 768, 256, 3), ("c544_32", 8 * 392 * 518, 544, 32, 3),
+              ("c64_32", 8 * 392 * 518, 64, 32, 3), ("c256_256_L4", 8 * 224 * 296, 512, 256, 3)]
+    for name, M, K, N, k in shapes:
+        if k == 1:
+            x = torch.randn(1, 1, M, K, device=dev).to(tdt)
+            y = torch.empty(1, 1, M, N, device=dev, dtype=tdt)
+            w = torch.randn(N, K) / K ** 0.5
+        else:
+            hw = {8 * 224 * 296: (224, 296), 8 * 392 * 518: (392, 518)}[M]
+            x = torch.randn(8, hw[0], hw[1], K, device=dev).to(tdt)
+            y = torch.empty(8, hw[0], hw[1], N, device=dev, dtype=tdt)
+            w = torch.randn(N, K, 3, 3) / (9 * K) ** 0.5
+        pw = pk.pack_conv(w, torch.zeros(N), dtype=tdt).to(dev)
+        ms = ops.conv(x, pw, y, pad=k // 2, _timed=5)
+        fl = 2.0 * M * N * K * k * k
+        print(f"{name:12s} M={M} K={K}x{k}x{k} N={N}: {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s", flush=True)
+        del x, y
 
 
 def roofline(dtype, dev):

@@ -520,14 +520,15 @@ int launch_big(const pf_conv_params& p, hipStream_t st) {
 // start of step g every wave issues a third of the NEXT chunk's halo and the weights of step g+1, which have
 // the whole step (72 MFMAs per wave) to land before the single vmcnt(0)+barrier that ends it.
 // -------------------------------------------------------------------------------------------------
-template <int FN, bool RELU_IN>
+template <int WN, int FM, int FN, bool RELU_IN>
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params p) {
   using T = bf16_t;
+  static_assert((8 / WN) * FM == 16, "8 waves cover the 16 tile rows");
   constexpr int TH = 16, TW = 32, HW_ = TW + 2, HROWS = (TH + 2) * HW_;   // 612 halo pixels
   constexpr int A_PIECES = (HROWS + 15) / 16;                               // 39 DMA pieces of 16 rows
   constexpr int A_PER_STEP = (A_PIECES + 2) / 3;                            // 13 pieces issued per step (3 steps / chunk)
   constexpr int A_BUF = 40960;                                              // >= 39*16*64
-  constexpr int BN = 64 * FN, W_TILE = BN * 64, W_PIECES = BN / 16;         // per-tap weight tile: BN rows x 64 B
+  constexpr int BN = WN * 32 * FN, W_TILE = BN * 64, W_PIECES = BN / 16;    // per-tap weight tile: BN rows x 64 B
   constexpr int W_STAGE = 3 * W_TILE, WQ = 3 * W_PIECES;                    // one filter ROW (3 taps) per step
   constexpr int WQ_PER_WAVE = (WQ + 7) / 8;                                 // 3 (BN 128) or 5 (BN 192)
   constexpr int LDS_W0 = 2 * A_BUF;
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params 
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
   const int nt = (p.Cout + BN - 1) / BN;
   const int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
@@ -608,18 +609,18 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params 
     }
   };
 
-  f32x16 acc[FN][4];
+  f32x16 acc[FN][FM];
 #pragma unroll
   for (int fn = 0; fn < FN; ++fn)
 #pragma unroll
-    for (int fm = 0; fm < 4; ++fm)
+    for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[fn][fm][e] = 0.f;
 
   const int fr = lane & 31, fh = lane >> 5;
-  int arow_base[4];
+  int arow_base[FM];
 #pragma unroll
-  for (int fm = 0; fm < 4; ++fm) arow_base[fm] = (4 * wm + fm) * HW_ + fr;
+  for (int fm = 0; fm < FM; ++fm) arow_base[fm] = (FM * wm + fm) * HW_ + fr;
   int w_off[FN], w_swz[FN];
 #pragma unroll
   for (int fn = 0; fn < FN; ++fn) {
@@ -654,12 +655,12 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params 
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int slot = (t << 1) | fh;
-        uint4 wf[FN], xf[4];
+        uint4 wf[FN], xf[FM];
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn)
           wf[fn] = *reinterpret_cast<const uint4*>(Wb + kx * W_TILE + w_off[fn] + ((slot ^ w_swz[fn]) << 4));
 #pragma unroll
-        for (int fm = 0; fm < 4; ++fm) {
+        for (int fm = 0; fm < FM; ++fm) {
           const int row = arow_base[fm] + tap_off;
           xf[fm] = *reinterpret_cast<const uint4*>(Ab + row * 64 + ((slot ^ ((row >> 2) & 3)) << 4));
           if constexpr (RELU_IN) xf[fm] = relu_vec<T>(xf[fm]);
@@ -667,7 +668,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params 
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn)
 #pragma unroll
-          for (int fm = 0; fm < 4; ++fm)
+          for (int fm = 0; fm < FM; ++fm)
             acc[fn][fm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[fn]),
                                                                   __builtin_bit_cast(bf16x8, xf[fm]), acc[fn][fm], 0, 0, 0);
       }
@@ -680,8 +681,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params 
 
   // ---- epilogue ----
 #pragma unroll
-  for (int fm = 0; fm < 4; ++fm) {
-    const int oy = ty0 + 4 * wm + fm, ox = tx0 + fr;
+  for (int fm = 0; fm < FM; ++fm) {
+    const int oy = ty0 + FM * wm + fm, ox = tx0 + fr;
     if (oy >= p.H || ox >= p.W) continue;
     const long opix = ((long)b * p.H + oy) * p.W + ox;
 #pragma unroll
@@ -728,17 +729,18 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params 
   }
 }
 
-template <int FN, bool RELU_IN>
+template <int WN, int FM, int FN, bool RELU_IN>
 int launch_halo(const pf_conv_params& p, hipStream_t st) {
-  constexpr int smem = 2 * 40960 + 2 * 3 * (64 * FN) * 64;
+  constexpr int BN = WN * 32 * FN;
+  constexpr int smem = 2 * 40960 + 2 * 3 * BN * 64;
   static bool attr_set = false;
-  auto kern = conv3x3_halo_kernel<FN, RELU_IN>;
+  auto kern = conv3x3_halo_kernel<WN, FM, FN, RELU_IN>;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   const long tiles = (long)p.B * ((p.H + 15) / 16) * ((p.W + 31) / 32);
-  const long nt = (p.Cout + 64 * FN - 1) / (64 * FN);
+  const long nt = (p.Cout + BN - 1) / BN;
   hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * nt)), dim3(512), smem, st, p);
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_LAUNCH;
 }
@@ -767,6 +769,13 @@ int launch_cfg(const pf_conv_params& p, hipStream_t st) {
 
 int g_force_small = -1;   // PF_IGEMM_SMALL=1 forces the 4-wave kernel everywhere (A/B measurements)
 
+// Tile selection for the generic implicit-GEMM kernels: a wave-quantisation-aware cost model.
+// A config with block tile BMxBN that admits `occ` blocks per CU processes 256*occ blocks per "round";
+// each round costs ~ BM*BN*occ (all configs sustain a similar per-CU rate), scaled by a small
+// efficiency factor for the narrow tiles.  At the ViT sizes (8296 tokens x 1024 channels) this is the
+// difference between 2 half-empty rounds of 256x128 tiles and 1 full round of 128x96 tiles.
+struct TileCfg { int bm, bn, occ; float eff; int id; };
+
 template <typename T>
 int dispatch(const pf_conv_params& p, hipStream_t st) {
   if (g_force_small < 0) {
@@ -776,33 +785,42 @@ int dispatch(const pf_conv_params& p, hipStream_t st) {
     int av = a ? atoi(a) : 0;
     hipMemcpyToSymbol(HIP_SYMBOL(pf_ablate), &av, sizeof(int));
   }
+  const long M = (long)p.B * p.OH * p.OW;
   if constexpr (sizeof(T) == 2) {
-    const long M = (long)p.B * p.OH * p.OW;
     if (g_force_small != 1 && g_force_small != 2 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.shuffle <= 1 &&
-        p.Cin % 32 == 0 && p.Cout >= 96 && p.H >= 16 && p.W >= 32 && M >= 2048) {
+        p.Cin % 32 == 0 && p.H >= 16 && p.W >= 32 && M >= 2048) {
+      if (p.Cout <= 32) return p.relu_in ? launch_halo<1, 2, 1, true>(p, st) : launch_halo<1, 2, 1, false>(p, st);
+      if (p.Cout <= 64) return p.relu_in ? launch_halo<1, 2, 2, true>(p, st) : launch_halo<1, 2, 2, false>(p, st);
       // channel tile: 192 when it wastes less than 128 (e.g. 544 -> 3x192 = 576 vs 5x128 = 640; 768 -> 4x192)
       const int pad128 = (p.Cout + 127) / 128 * 128, pad192 = (p.Cout + 191) / 192 * 192;
-      if (pad192 <= pad128) return p.relu_in ? launch_halo<3, true>(p, st) : launch_halo<3, false>(p, st);
-      return p.relu_in ? launch_halo<2, true>(p, st) : launch_halo<2, false>(p, st);
+      if (pad192 <= pad128) return p.relu_in ? launch_halo<2, 4, 3, true>(p, st) : launch_halo<2, 4, 3, false>(p, st);
+      return p.relu_in ? launch_halo<2, 4, 2, true>(p, st) : launch_halo<2, 4, 2, false>(p, st);
     }
-    if (g_force_small != 1 && p.Cout >= 96 && M >= 2048)
-      return p.relu_in ? launch_big<true>(p, st) : launch_big<false>(p, st);
   }
-  // pick the channel tile minimising padded work / tile efficiency
-  const int cand[5] = {128, 96, 64, 32, 16};
-  const float eff[5] = {1.0f, 0.97f, 0.9f, 0.8f, 0.6f};
-  int best = 0;
-  float best_cost = 1e30f;
-  for (int i = 0; i < 5; ++i) {
-    const int padded = (p.Cout + cand[i] - 1) / cand[i] * cand[i];
-    const float c = padded / eff[i];
-    if (c < best_cost) { best_cost = c; best = i; }
+  const TileCfg cfgs[6] = {{256, 128, 1, 1.0f, 0}, {128, 128, 2, 1.0f, 1}, {128, 96, 2, 0.97f, 2},
+                           {128, 64, 3, 0.96f, 3}, {256, 32, 2, 0.75f, 4}, {256, 16, 2, 0.5f, 5}};
+  static int force_cfg = -2;
+  if (force_cfg == -2) {
+    const char* e = getenv("PF_IGEMM_CFG");
+    force_cfg = e ? atoi(e) : -1;
   }
-  switch (cand[best]) {
-    case 128: return launch_cfg<T, 128, 128, 2, 2>(p, st);
-    case 96: return launch_cfg<T, 128, 96, 2, 2>(p, st);
-    case 64: return launch_cfg<T, 128, 64, 2, 2>(p, st);
-    case 32: return launch_cfg<T, 256, 32, 4, 1>(p, st);
+  int best = -1;
+  double best_cost = 1e300;
+  for (int i = 0; i < 6; ++i) {
+    const TileCfg& c = cfgs[i];
+    if (c.id == 0 && (sizeof(T) != 2 || g_force_small == 1 || p.Cout < 96)) continue;   // big kernel: bf16 only
+    const long blocks = ((M + c.bm - 1) / c.bm) * ((p.Cout + c.bn - 1) / c.bn);
+    // makespan ~ (blocks / slots + one block of tail) * time per block
+    const double cost = ((double)blocks / (256.0 * c.occ) + 1.0) * c.bm * c.bn * c.occ / c.eff;
+    if (cost < best_cost) { best_cost = cost; best = c.id; }
+  }
+  if (force_cfg >= 0 && !(force_cfg == 0 && sizeof(T) != 2)) best = force_cfg;
+  switch (best) {
+    case 0: if constexpr (sizeof(T) == 2) return p.relu_in ? launch_big<true>(p, st) : launch_big<false>(p, st);
+    case 1: return launch_cfg<T, 128, 128, 2, 2>(p, st);
+    case 2: return launch_cfg<T, 128, 96, 2, 2>(p, st);
+    case 3: return launch_cfg<T, 128, 64, 2, 2>(p, st);
+    case 4: return launch_cfg<T, 256, 32, 4, 1>(p, st);
     default: return launch_cfg<T, 256, 16, 4, 1>(p, st);
   }
 }

@@ -232,6 +232,11 @@ class HipOps:
         check(_L.pf_pack_fusion_input(_p(cdepth), _p(fdepth), _p(crops), _p(y), B, h, w, _dt(y), _stream()), "pf_pack_fusion_input")
 
     @staticmethod
+    def copy_plane(src, dst):
+        """dst[...] = src[:, 0] for float32 depth planes (device-to-device, async on the current stream)"""
+        dst.copy_(src[:, 0], non_blocking=True)
+
+    @staticmethod
     def nhwc_to_nchw(x, Cc=None):
         B, H, W, Ct = x.shape
         Cc = Cc or Ct

@@ -191,6 +191,11 @@ class FakeOps:
         y[..., 5:] = 0
 
     @staticmethod
+    def copy_plane(src, dst):
+        """dst[...] = src[:, 0] for float32 depth planes (device-to-device, async on the current stream)"""
+        dst.copy_(src[:, 0], non_blocking=True)
+
+    @staticmethod
     def nhwc_to_nchw(x, Cc=None):
         Cc = Cc or x.shape[-1]
         return x[..., :Cc].float().permute(0, 3, 1, 2).contiguous()

@@ -124,6 +124,18 @@ def conv_big_3x3_n160(dt):
     return _conv_case(dt, 3, 30, 41, 160, 160, 3, pad=1, act="relu", seed=13)
 
 
+def conv_halo_n32(dt):
+    return _conv_case(dt, 2, 40, 52, 64, 32, 3, pad=1, act="relu", y_extra=16, seed=21)
+
+
+def conv_halo_n64_res(dt):
+    return _conv_case(dt, 2, 33, 67, 160, 64, 3, pad=1, relu_in=True, res=True, seed=22)
+
+
+def conv_halo_n32_cin544(dt):
+    return _conv_case(dt, 1, 50, 70, 544, 32, 3, pad=1, act="relu", seed=23)
+
+
 def conv_big_stride2(dt):
     return _conv_case(dt, 1, 96, 100, 96, 192, 3, stride=2, pad=1, seed=14)
 
@@ -374,6 +386,7 @@ CHECKS = {
     "conv1x1_cout80": conv1x1_cout80, "conv1x1_cout16": conv1x1_cout16, "conv3x3_nobias_48": conv3x3_nobias_48,
     "conv_big_3x3_rcu": conv_big_3x3_rcu, "conv_big_3x3_n544_views": conv_big_3x3_n544_views,
     "conv_big_3x3_n160": conv_big_3x3_n160, "conv_big_stride2": conv_big_stride2,
+    "conv_halo_n32": conv_halo_n32, "conv_halo_n64_res": conv_halo_n64_res, "conv_halo_n32_cin544": conv_halo_n32_cin544,
     "conv_big_gemm_scale_inplace": conv_big_gemm_scale_inplace, "conv_big_gemm_gelu_k1024": conv_big_gemm_gelu_k1024,
     "conv_big_transpose": conv_big_transpose,
     "conv_transpose": conv_transpose, "patch_embed_tokens": patch_embed_tokens, "layernorm": layernorm,

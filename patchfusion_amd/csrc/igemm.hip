@@ -649,6 +649,36 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params 
     // ---- multiply filter row ky (three taps) of this chunk ----
     const char* Ab = smem + (chunk & 1) * A_BUF;
     const char* Wb = smem + LDS_W0 + (g & 1) * W_STAGE;
+    if constexpr (FN * FM <= 8) {
+      // software-pipelined fragment reads (enough registers when the accumulator tile is <= 8 fragments):
+      // the ds_reads of sub-step u+1 = (kx, t) are in flight while the MFMAs of sub-step u execute
+      uint4 wf[2][FN], xf[2][FM];
+      auto load_frags = [&](int u, uint4 (&w)[FN], uint4 (&x)[FM]) {
+        const int kx = u >> 1, t = u & 1;
+        const int tap_off = ky * HW_ + kx;
+        const int slot = (t << 1) | fh;
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn)
+          w[fn] = *reinterpret_cast<const uint4*>(Wb + kx * W_TILE + w_off[fn] + ((slot ^ w_swz[fn]) << 4));
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+          const int row = arow_base[fm] + tap_off;
+          x[fm] = *reinterpret_cast<const uint4*>(Ab + row * 64 + ((slot ^ ((row >> 2) & 3)) << 4));
+          if constexpr (RELU_IN) x[fm] = relu_vec<T>(x[fm]);
+        }
+      };
+      load_frags(0, wf[0], xf[0]);
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        if (u + 1 < 6) load_frags(u + 1, wf[(u + 1) & 1], xf[(u + 1) & 1]);
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+          for (int fm = 0; fm < FM; ++fm)
+            acc[fn][fm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[u & 1][fn]),
+                                                                  __builtin_bit_cast(bf16x8, xf[u & 1][fm]), acc[fn][fm], 0, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       const int tap_off = ky * HW_ + kx;
@@ -672,6 +702,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params 
             acc[fn][fm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[fn]),
                                                                   __builtin_bit_cast(bf16x8, xf[fm]), acc[fn][fm], 0, 0, 0);
       }
+    }
     }
     // ---- everything issued this step (weights of g+1, halo pieces) has a whole step of MFMA to land ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -793,6 +824,9 @@ int dispatch(const pf_conv_params& p, hipStream_t st) {
       if (p.Cout <= 64) return p.relu_in ? launch_halo<1, 2, 2, true>(p, st) : launch_halo<1, 2, 2, false>(p, st);
       // channel tile: 192 when it wastes less than 128 (e.g. 544 -> 3x192 = 576 vs 5x128 = 640; 768 -> 4x192)
       const int pad128 = (p.Cout + 127) / 128 * 128, pad192 = (p.Cout + 191) / 192 * 192;
+      static int fn_force = -1;
+      if (fn_force < 0) { const char* e = getenv("PF_HALO_FN"); fn_force = e ? atoi(e) : 0; }
+      if (fn_force == 2) return p.relu_in ? launch_halo<2, 4, 2, true>(p, st) : launch_halo<2, 4, 2, false>(p, st);
       if (pad192 <= pad128) return p.relu_in ? launch_halo<2, 4, 3, true>(p, st) : launch_halo<2, 4, 3, false>(p, st);
       return p.relu_in ? launch_halo<2, 4, 2, true>(p, st) : launch_halo<2, 4, 2, false>(p, st);
     }

@@ -550,60 +550,49 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params 
   const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
   const char* zero = reinterpret_cast<const char*>(pf_zero_page);
 
-  // ---- DMA sources.  A piece = 16 halo rows x 64 B: lane L -> row 16*piece + (L>>2), physical slot L&3,
-  // fetching logical slot (L&3) ^ ((row>>2)&3).  In step ky of a chunk, wave w issues pieces
-  // ky*13 + w and ky*13 + w + 8 of the NEXT chunk's halo (when < 13 within the step and < 39 overall). ----
-  unsigned a_src[3][2];   // byte offsets from p.x (tensors are < 4 GiB); ~0u = outside the image
+  // ---- DMA issue (LOADER waves only).  The two waves that share a SIMD are waves w and w+4; only waves 0..3
+  // issue the LDS-DMAs of a step, so while they spend ~1000 cycles on address arithmetic + DMA issue their
+  // partners 4..7 already run MFMAs: the matrix pipe is never idle because BOTH co-resident waves are in a
+  // non-MFMA phase (measured: SQ_WAIT_ANY 41 % with symmetric issue).
+  // A piece = 16 halo rows x 64 B: lane L -> row 16*piece + (L>>2), physical slot L&3, fetching logical slot
+  // (L&3) ^ ((row>>2)&3).  Step ky of a chunk brings pieces [13 ky, 13 ky + 13) of the NEXT chunk's halo. ----
+  const bool loader = wave < 4;
   const char* xbase = reinterpret_cast<const char*>(xg);
   const char* wbase = reinterpret_cast<const char*>(wg);
-#pragma unroll
-  for (int st = 0; st < 3; ++st)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int q = wave + 8 * i;
-      const int piece = st * A_PER_STEP + q;
-      const int row = piece * 16 + (lane >> 2);
-      const int jl = (lane & 3) ^ ((row >> 2) & 3);
-      const int hy = row / HW_, hx = row - hy * HW_;
-      const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
-      const bool ok = q < A_PER_STEP && piece < A_PIECES && row < HROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      a_src[st][i] = ok ? (unsigned)(((((long)b * p.H + iy) * p.W + ix) * p.x_ld + jl * 8) * 2) : ~0u;
-    }
-  // weight pieces of one step: q = kx*W_PIECES + piece16 ; wave w issues q = w, w+8, ...
-  unsigned w_src[WQ_PER_WAVE];   // byte offsets from p.w; ~0u = beyond the packed rows
-#pragma unroll
-  for (int i = 0; i < WQ_PER_WAVE; ++i) {
-    const int q = wave + 8 * i;
-    const int kxq = q / W_PIECES, piece = q - kxq * W_PIECES;
-    const int row = piece * 16 + (lane >> 2);
-    const int jl = (lane & 3) ^ ((row >> 2) & 3);
-    const bool ok = q < WQ && (n0 + row) < p.w_rows;
-    w_src[i] = ok ? (unsigned)(((long)(n0 + row) * p.Kpad + (long)kxq * p.Cin + jl * 8) * 2) : ~0u;
-  }
+  const int l_row = lane >> 2, l_slot = lane & 3;
   const int nchunks = p.Cin / 32;
   const int G = nchunks * 3;                 // steps: (chunk, ky)
   const unsigned smem_base = lds_addr(smem);
 
-  auto issue_a = [&](int st, int chunk) {    // this wave's halo pieces of step-slot st for channel chunk `chunk`
+  auto issue_a = [&](int st, int chunk) {    // halo pieces of step-slot st for channel chunk `chunk`
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int q = wave + 8 * i;
-      if (q < A_PER_STEP && st * A_PER_STEP + q < A_PIECES) {
-        const unsigned off = st == 0 ? a_src[0][i] : (st == 1 ? a_src[1][i] : a_src[2][i]);
-        const char* src = off != ~0u ? xbase + off + (long)chunk * 64 : zero;
-        glds16(src, smem_base + (chunk & 1) * A_BUF + (st * A_PER_STEP + q) * 1024);
+    for (int i = 0; i < (A_PER_STEP + 3) / 4; ++i) {
+      const int q = wave + 4 * i;
+      const int piece = st * A_PER_STEP + q;
+      if (q < A_PER_STEP && piece < A_PIECES) {
+        const int row = piece * 16 + l_row;
+        const int jl = l_slot ^ ((row >> 2) & 3);
+        const int hy = row / HW_, hx = row - hy * HW_;
+        const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+        const bool ok = row < HROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const char* src = ok ? xbase + ((((long)b * p.H + iy) * p.W + ix) * p.x_ld + jl * 8 + chunk * 32) * 2 : zero;
+        glds16(src, smem_base + (chunk & 1) * A_BUF + piece * 1024);
       }
     }
   };
   auto issue_w = [&](int g) {                // weight row-tile of step g = chunk*3 + ky -> ring slot g&1
     const int chunk = g / 3, kyy = g - chunk * 3;
-    const long off = ((long)(kyy * 3) * p.Cin + chunk * 32) * 2;
+    const long koff = (long)(kyy * 3) * p.Cin + chunk * 32;
     const unsigned dst = smem_base + LDS_W0 + (g & 1) * W_STAGE;
 #pragma unroll
-    for (int i = 0; i < WQ_PER_WAVE; ++i) {
-      const int q = wave + 8 * i;
+    for (int i = 0; i < (WQ + 3) / 4; ++i) {
+      const int q = wave + 4 * i;
       if (q < WQ) {
-        const char* src = w_src[i] != ~0u ? wbase + w_src[i] + off : zero;
+        const int kxq = q / W_PIECES, piece = q - kxq * W_PIECES;
+        const int row = piece * 16 + l_row;
+        const int jl = l_slot ^ ((row >> 2) & 3);
+        const bool ok = (n0 + row) < p.w_rows;
+        const char* src = ok ? wbase + ((long)(n0 + row) * p.Kpad + koff + (long)kxq * p.Cin + jl * 8) * 2 : zero;
         glds16(src, dst + q * 1024);
       }
     }
@@ -630,22 +619,22 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params 
   }
 
   // ---- prologue: whole halo of chunk 0 and the weight rows of step 0 ----
-  issue_a(0, 0);
-  issue_a(1, 0);
-  issue_a(2, 0);
-  issue_w(0);
+  if (loader) {
+    issue_a(0, 0);
+    issue_a(1, 0);
+    issue_a(2, 0);
+    issue_w(0);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   int chunk = 0, ky = 0;
   for (int g = 0; g < G; ++g) {
-    // ---- issue: a third of the next chunk's halo, then the weight rows of step g+1 (other ring slot) ----
-    if (chunk + 1 < nchunks) {
-      if (ky == 0) issue_a(0, chunk + 1);
-      else if (ky == 1) issue_a(1, chunk + 1);
-      else issue_a(2, chunk + 1);
+    // ---- loader waves: a third of the next chunk's halo, then the weight rows of step g+1 (other ring slot) ----
+    if (loader) {
+      if (chunk + 1 < nchunks) issue_a(ky, chunk + 1);
+      if (g + 1 < G) issue_w(g + 1);
     }
-    if (g + 1 < G) issue_w(g + 1);
     // ---- multiply filter row ky (three taps) of this chunk ----
     const char* Ab = smem + (chunk & 1) * A_BUF;
     const char* Wb = smem + LDS_W0 + (g & 1) * W_STAGE;

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpf_hip.so")
+LIB_PATH = os.environ.get("PF_LIB_PATH") or os.path.join(_HERE, "libpf_hip.so")   # PF_LIB_PATH: kernel-tuning builds only
 
 vp, ci, cf, cl = C.c_void_p, C.c_int, C.c_float, C.c_long
 

@@ -631,10 +631,12 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params 
   int chunk = 0, ky = 0;
   for (int g = 0; g < G; ++g) {
     // ---- loader waves: a third of the next chunk's halo, then the weight rows of step g+1 (other ring slot) ----
+#ifndef PF_ABL_NODMA   // (compile-time measurement variants: make ablate; never part of libpf_hip.so)
     if (loader) {
       if (chunk + 1 < nchunks) issue_a(ky, chunk + 1);
       if (g + 1 < G) issue_w(g + 1);
     }
+#endif
     // ---- multiply filter row ky (three taps) of this chunk ----
     const char* Ab = smem + (chunk & 1) * A_BUF;
     const char* Wb = smem + LDS_W0 + (g & 1) * W_STAGE;
@@ -675,6 +677,13 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params 
       for (int t = 0; t < 2; ++t) {
         const int slot = (t << 1) | fh;
         uint4 wf[FN], xf[FM];
+#ifdef PF_ABL_NOLDS
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) { wf[fn] = make_uint4(slot, tap_off, lane, fn); asm volatile("" : "+v"(wf[fn].x)); }
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) { xf[fm] = make_uint4(slot, tap_off, lane, fm); asm volatile("" : "+v"(xf[fm].x)); }
+        (void)Ab; (void)Wb;
+#else
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn)
           wf[fn] = *reinterpret_cast<const uint4*>(Wb + kx * W_TILE + w_off[fn] + ((slot ^ w_swz[fn]) << 4));
@@ -684,6 +693,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params 
           xf[fm] = *reinterpret_cast<const uint4*>(Ab + row * 64 + ((slot ^ ((row >> 2) & 3)) << 4));
           if constexpr (RELU_IN) xf[fm] = relu_vec<T>(xf[fm]);
         }
+#endif
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn)
 #pragma unroll
@@ -695,7 +705,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params 
     }
     // ---- everything issued this step (weights of g+1, halo pieces) has a whole step of MFMA to land ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef PF_ABL_NOBAR
     __syncthreads();
+#endif
     if (++ky == 3) { ky = 0; ++chunk; }
   }
 

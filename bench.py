@@ -176,31 +176,39 @@ def roofline(dtype, dev):
     flops = 2.0 * B * H * W * 9 * C * C
     ach = flops / (ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[dtype]
-    return {"bound": "mfma", "kernel": "conv_igemm_kernel 3x3 544->544 @ 8x392x518 (GuidedFusion up-conv, largest op)",
+    traffic = None   # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside bench.py): profiles/r1_pmc_dominant_kernel.json
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_dominant_kernel.json")) as f:
+            traffic = json.load(f)["derived"]["traffic_bytes"] if dtype == "bf16" else None
+    except Exception:
+        pass
+    return {"bound": "mfma", "kernel": "conv3x3_halo_kernel<2,4,3> (bf16) / conv_igemm_kernel (fp32): 3x3 544->544 @ 8x392x518, the GuidedFusion up-conv = largest op",
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-            "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "traffic": None}
+            "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "traffic": traffic}
 
 
 def cpu_baseline(cfg, sd, img):
-    """The oracle (CPU restatement of the reference, kind 'port') on the host cores, bounded sample:
-    ONE fine-branch forward (ZoeDepth branch: ViT-L + DPT + bins head) of one 392x518 tile of the same
-    workload, scaled to patches/s by the algorithmic FLOP share of the branch in one tile
-    (970.1 GF of 4029.9 GF per tile)."""
+    """The oracle (CPU restatement of the reference, kind 'port') on the host cores, bounded sample: the
+    ViT-L encoder forward of ONE 392x518 tile of the same workload (733.3 GFLOP of the 4029.9 GFLOP of a tile,
+    BASELINE.md section 3), scaled to patches/s by that FLOP share.  Threads are capped at 64: the full 256
+    hardware threads of the GPU box oversubscribe torch's CPU kernels (measured 108 s for one branch forward)."""
     from oracle import pf_oracle
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(cores)
     orc = pf_oracle.Oracle(cfg, sd)
     with torch.no_grad():
         hr, wr = cfg["image_raw_shape"][0] // cfg["patch_split_num"][0], cfg["image_raw_shape"][1] // cfg["patch_split_num"][1]
         crop = orc.resizer(img[:, :, :hr, :wr])
+        mean = torch.tensor(pf_oracle.IMAGENET_MEAN).view(1, 3, 1, 1)
+        std = torch.tensor(pf_oracle.IMAGENET_STD).view(1, 3, 1, 1)
         t0 = time.perf_counter()
-        pf_oracle.branch_forward(sd, "fine_branch.", crop, cfg["fine_branch"])
+        pf_oracle.vit_forward(sd, "fine_branch.core.core.pretrained.", (crop - mean) / std, cfg["fine_branch"]["midas_model_type"])
         dt = time.perf_counter() - t0
-    share = 970.1 / 4029.9
-    log(f"cpu baseline: branch forward {dt:.1f}s on {cores} cores")
+    share = 733.3 / 4029.9
+    log(f"cpu baseline: ViT-L encoder forward {dt:.1f}s on {cores} threads")
     return {"value": round(share / dt, 5), "unit": "patches/s", "cores": cores, "kind": "port",
-            "sample": f"1 fine-branch forward (ViT-L+DPT+bins head, 970.1 of the 4029.9 GFLOP of one tile) of the same "
-                      f"workload: {dt:.1f} s on {cores} threads, scaled by the FLOP share"}
+            "sample": f"ViT-L encoder forward of 1 tile (733.3 of the 4029.9 GFLOP of one tile) of the same workload: "
+                      f"{dt:.1f} s on {cores} threads, scaled by the FLOP share"}
 
 
 if __name__ == "__main__":

@@ -309,6 +309,159 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const T* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 attention, 32 queries per wave on v_mfma_f32_32x32x16_bf16 (the f32 path keeps the 16-query kernel
+// above).  Block = 4 waves = 128 queries; KV tiles of 64 keys, double-buffered in LDS (one barrier per tile,
+// next tile's global loads in flight during the MFMAs).  S^T = K Q^T: lane (q = l&31, h = l>>5) holds for its
+// query the keys f*32 + 8j + 4h + i (register 4j+i of fragment f), so max/sum are in-lane + one shuffle, and
+// registers 8jj..8jj+7 of fragment f are exactly the 8 bf16 the PV MFMA wants as its B operand for the
+// 16-key step (f,jj) - with the V^T fragment reading the same keys (two 8-byte reads).
+// LDS: K rows 128 B, slot ^= (row>>1)&7 (conflict-free b128 fragment reads); V^T rows 128 B with the same
+// slot swizzle plus the two 8-byte halves of a slot swapped for rows 16..31 (mod 32), which makes the 8-byte
+// fragment reads of a 32-lane group hit 32 distinct 8-byte bank pairs.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+__global__ __launch_bounds__(256) void vit_attention32_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                              const bf16_t* __restrict__ vt, bf16_t* __restrict__ out, int B,
+                                                              int S, int Sp, int Hh) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * 2 * 64 * 128];   // [stage][K | V^T][64 rows][128 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int bh = blockIdx.y, b = bh / Hh, h = bh % Hh;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int D = Hh * 64;
+  const bf16_t* qb = q + (long)bh * S * 64;
+  const bf16_t* kb = k + (long)bh * S * 64;
+  const bf16_t* vb = vt + (long)bh * 64 * Sp;
+
+  const int qi = min(q0 + fr, S - 1);
+  uint4 qf[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) qf[t] = *reinterpret_cast<const uint4*>(qb + (long)qi * 64 + t * 16 + fh * 8);
+
+  f32x16_t o[2];
+#pragma unroll
+  for (int fd = 0; fd < 2; ++fd)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[fd][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // staging: 64 rows x 8 vectors per matrix = 512 vectors; thread -> rows (tid>>3) and (tid>>3)+32, vector tid&7
+  const int sj = tid & 7, sr = tid >> 3;
+  uint4 kreg[2], vreg[2];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = sr + 32 * i;
+      const int key = kt * 64 + row;
+      kreg[i] = make_uint4(0, 0, 0, 0);
+      if (key < S) kreg[i] = *reinterpret_cast<const uint4*>(kb + (long)key * 64 + sj * 8);
+      vreg[i] = *reinterpret_cast<const uint4*>(vb + (long)row * Sp + kt * 64 + sj * 8);
+    }
+  };
+  auto lstore = [&](int stage) {
+    char* Ks = lds + stage * (2 * 64 * 128);
+    char* Vs = Ks + 64 * 128;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = sr + 32 * i;
+      const int ps = (sj ^ ((row >> 1) & 7)) << 4;
+      *reinterpret_cast<uint4*>(Ks + row * 128 + ps) = kreg[i];
+      uint4 v = vreg[i];
+      if ((row >> 4) & 1) v = make_uint4(v.z, v.w, v.x, v.y);   // swap the 8-byte halves
+      *reinterpret_cast<uint4*>(Vs + row * 128 + ps) = v;
+    }
+  };
+
+  const int ntiles = (S + 63) / 64;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int kswz = (fr >> 1) & 7;          // fragment rows are f*32 + fr
+  const int vhalf = ((fr >> 4) & 1);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const bool more = kt + 1 < ntiles;
+    if (more) gload(kt + 1);
+    const char* Ks = lds + (kt & 1) * (2 * 64 * 128);
+    const char* Vs = Ks + 64 * 128;
+    // ---- S^T = K Q^T : 2 key fragments x 4 d-steps ----
+    f32x16_t sc[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sc[f][e] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const uint4 a = *reinterpret_cast<const uint4*>(Ks + (f * 32 + fr) * 128 + ((((t << 1) | fh) ^ kswz) << 4));
+        sc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, qf[t]), sc[f], 0, 0, 0);
+      }
+    }
+    // ---- online softmax (query = lane & 31); register 4j+i of fragment f is key kt*64 + f*32 + 8j + 4fh + i ----
+    float mx = -INFINITY;
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 64 + f * 32 + 8 * (r >> 2) + 4 * fh + (r & 3);
+        if (key >= S) sc[f][r] = -INFINITY;
+        mx = fmaxf(mx, sc[f][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pe = __expf(sc[f][r] - m_new);
+        sc[f][r] = pe;
+        psum += pe;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int fd = 0; fd < 2; ++fd)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[fd][e] *= alpha;
+    // ---- O^T += V^T P^T : 4 steps of 16 keys (f, jj) x 2 d-fragments ----
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        uint4 pb;
+        pb.x = (uint32_t)f2bf(sc[f][8 * jj + 0]) | ((uint32_t)f2bf(sc[f][8 * jj + 1]) << 16);
+        pb.y = (uint32_t)f2bf(sc[f][8 * jj + 2]) | ((uint32_t)f2bf(sc[f][8 * jj + 3]) << 16);
+        pb.z = (uint32_t)f2bf(sc[f][8 * jj + 4]) | ((uint32_t)f2bf(sc[f][8 * jj + 5]) << 16);
+        pb.w = (uint32_t)f2bf(sc[f][8 * jj + 6]) | ((uint32_t)f2bf(sc[f][8 * jj + 7]) << 16);
+        // keys f*32+16jj+4fh..+3 -> logical slot 4f+2jj, 8-byte half fh ; keys +8 -> slot 4f+2jj+1, half fh
+        const int s0 = 4 * f + 2 * jj;
+#pragma unroll
+        for (int fd = 0; fd < 2; ++fd) {
+          const char* rowp = Vs + (fd * 32 + fr) * 128 + ((fh ^ vhalf) << 3);
+          const uint2 lo = *reinterpret_cast<const uint2*>(rowp + ((s0 ^ kswz) << 4));
+          const uint2 hi = *reinterpret_cast<const uint2*>(rowp + (((s0 + 1) ^ kswz) << 4));
+          const uint4 a = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          o[fd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, pb), o[fd], 0, 0, 0);
+        }
+      }
+    if (more) lstore((kt + 1) & 1);
+    __syncthreads();
+  }
+  float l = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l;
+  const int qo = q0 + fr;
+  if (qo < S) {
+    bf16_t* dst = out + ((long)b * S + qo) * D + h * 64 + 4 * fh;
+#pragma unroll
+    for (int fd = 0; fd < 2; ++fd)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        store4(dst + fd * 32 + 8 * j, o[fd][4 * j] * inv, o[fd][4 * j + 1] * inv, o[fd][4 * j + 2] * inv, o[fd][4 * j + 3] * inv);
+  }
+}
+
 inline int grid_for(long n, int block) {
   long g = (n + block - 1) / block;
   return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
@@ -360,7 +513,10 @@ extern "C" int pf_vit_attention(const void* q, const void* k, const void* vt, vo
                                 int dtype, void* stream) {
   if (!q || !k || !vt || !out || Sp % 64 || Sp < S) return PF_ERR_ARG;
   dim3 grid((S + 63) / 64, B * Hh);
-  if (dtype == PF_DTYPE_BF16) hipLaunchKernelGGL(vit_attention_kernel<bf16_t>, grid, dim3(256), 0, ST(stream), (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, B, S, Sp, Hh);
+  static int old_attn = -1;
+  if (old_attn < 0) { const char* e = getenv("PF_ATTN_OLD"); old_attn = (e && e[0] == '1') ? 1 : 0; }
+  if (dtype == PF_DTYPE_BF16 && !old_attn) hipLaunchKernelGGL(vit_attention32_kernel, dim3((S + 127) / 128, B * Hh), dim3(256), 0, ST(stream), (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, B, S, Sp, Hh);
+  else if (dtype == PF_DTYPE_BF16) hipLaunchKernelGGL(vit_attention_kernel<bf16_t>, grid, dim3(256), 0, ST(stream), (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, B, S, Sp, Hh);
   else hipLaunchKernelGGL(vit_attention_kernel<float>, grid, dim3(256), 0, ST(stream), (const float*)q, (const float*)k, (const float*)vt, (float*)out, B, S, Sp, Hh);
   return ok();
 }

@@ -111,6 +111,9 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
         self.compute_dtype = _DTYPES[compute_dtype or config.get("compute_dtype", "fp32")]
         self.shard_patches = shard_patches
         self._ops = ops
+        import os as _os
+        self.overlap_coarse = bool(config.get("overlap_coarse", True)) and _os.environ.get("PF_OVERLAP", "1") != "0"
+        self._side_stream = None
         self._engine = None
         self._coarse_state = None
         if config.get("load_branch", False) and config.get("pretrain_model"):
@@ -238,7 +241,7 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
         return hit
 
     @torch.no_grad()
-    def _predict_tiles(self, image_hr, tiles, tile_cfg, process_num):
+    def _predict_tiles(self, image_hr, tiles, tile_cfg, process_num, coarse_ready=None):
         """Per-tile depth [P,h,w] f32 for this rank's shard (all tiles when not distributed)."""
         ops, dev = self.ops, self._device
         ph, pw = self.patch_process_shape
@@ -250,12 +253,20 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
         preds = ops.empty((n, ph, pw), torch.float32, dev)
         img = image_hr[0].contiguous().float()
         bt, rois = self._tile_tables(tiles, tile_cfg)
+        nets = self._engine
         for s in range(lo, hi, process_num):
             e = min(s + process_num, hi)
             crops = ops.empty((e - s, 3, ph, pw), torch.float32, dev)
             ops.crop_resize(img, bt[s:e], crops)
-            d = self.infer_forward(crops, rois[s:e])
-            ops.copy_plane(d, preds[s:e])
+            # fine branch does not depend on the coarse pass: for the first batch it runs while the coarse
+            # branch + G2L (batch 1, low occupancy) execute on the side stream
+            fdepth, ffeats = nets["fine"].forward(ops, crops)
+            if coarse_ready is not None:
+                torch.cuda.current_stream().wait_event(coarse_ready)
+                coarse_ready = None
+            st = self._coarse_state
+            d = nets["fusion"].forward(ops, crops, rois[s:e], fdepth, ffeats, st["depth"], st["feats"], st["g2l"])
+            ops.copy_plane(d.unsqueeze(1), preds[s:e])
         if world > 1:
             from .dist import all_gather_shards
             preds = all_gather_shards(preds, n, world)
@@ -308,9 +319,21 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
             tile_cfg = self.prepare_tile_cfg(tile_cfg['image_raw_shape'], tile_cfg['patch_split_num'])
         assert image_hr.shape[0] == 1
         self._ensure_engine()
-        self._coarse(image_lr)
+        coarse_ready = None
+        if image_hr.is_cuda and self.overlap_coarse:
+            # coarse branch + G2L on a side stream, overlapped with the first fine-branch batch
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=image_hr.device)
+            main = torch.cuda.current_stream()
+            self._side_stream.wait_stream(main)
+            with torch.cuda.stream(self._side_stream):
+                self._coarse(image_lr)
+                coarse_ready = torch.cuda.Event()
+                coarse_ready.record(self._side_stream)
+        else:
+            self._coarse(image_lr)
         tiles = tiling.tile_schedule(tile_cfg, self.patch_process_shape, cai_mode, process_num)
-        preds = self._predict_tiles(image_hr, tiles, tile_cfg, process_num)
+        preds = self._predict_tiles(image_hr, tiles, tile_cfg, process_num, coarse_ready)
         avg = self._stitch(preds, tiles, tile_cfg)
         if cai_mode[0] == 'r' and not any(t['phase'] == 'random' for t in tiles):
             # r<N> with N < process_num: the reference still resizes the map to the raw resolution

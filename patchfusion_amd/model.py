@@ -17,6 +17,7 @@ Multi-GPU: when torch.distributed is initialised and ``shard_patches=True`` the 
 are sharded over ranks (contiguous chunks) and the per-patch depths are all-gathered over RCCL.
 """
 from collections import OrderedDict
+from contextlib import nullcontext as _nullcontext
 
 import torch
 import torch.nn as nn
@@ -113,7 +114,9 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
         self._ops = ops
         import os as _os
         self.overlap_coarse = bool(config.get("overlap_coarse", True)) and _os.environ.get("PF_OVERLAP", "1") != "0"
+        self.overlap_batches = bool(config.get("overlap_batches", True)) and _os.environ.get("PF_OVERLAP_BATCHES", "1") != "0"
         self._side_stream = None
+        self._aux_stream = None
         self._engine = None
         self._coarse_state = None
         if config.get("load_branch", False) and config.get("pretrain_model"):
@@ -254,19 +257,31 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
         img = image_hr[0].contiguous().float()
         bt, rois = self._tile_tables(tiles, tile_cfg)
         nets = self._engine
-        for s in range(lo, hi, process_num):
+        # consecutive batches alternate between the current stream and an auxiliary stream: the low-occupancy
+        # kernels of one batch (coarse pyramid levels L0..L2, B x 14x19 ... 56x74 maps) fill the gaps of the other
+        use_aux = img.is_cuda and self.overlap_batches and (hi - lo) > process_num
+        main = torch.cuda.current_stream() if img.is_cuda else None
+        if use_aux:
+            if self._aux_stream is None:
+                self._aux_stream = torch.cuda.Stream(device=dev)
+            self._aux_stream.wait_stream(main)
+        for bi, s in enumerate(range(lo, hi, process_num)):
             e = min(s + process_num, hi)
-            crops = ops.empty((e - s, 3, ph, pw), torch.float32, dev)
-            ops.crop_resize(img, bt[s:e], crops)
-            # fine branch does not depend on the coarse pass: for the first batch it runs while the coarse
-            # branch + G2L (batch 1, low occupancy) execute on the side stream
-            fdepth, ffeats = nets["fine"].forward(ops, crops)
-            if coarse_ready is not None:
-                torch.cuda.current_stream().wait_event(coarse_ready)
-                coarse_ready = None
-            st = self._coarse_state
-            d = nets["fusion"].forward(ops, crops, rois[s:e], fdepth, ffeats, st["depth"], st["feats"], st["g2l"])
-            ops.copy_plane(d.unsqueeze(1), preds[s:e])
+            stream = self._aux_stream if (use_aux and bi % 2 == 1) else main
+            ctx = torch.cuda.stream(stream) if img.is_cuda else _nullcontext()
+            with ctx:
+                crops = ops.empty((e - s, 3, ph, pw), torch.float32, dev)
+                ops.crop_resize(img, bt[s:e], crops)
+                # the fine branch does not depend on the coarse pass: it runs while the coarse branch + G2L
+                # (batch 1, low occupancy) execute on the side stream
+                fdepth, ffeats = nets["fine"].forward(ops, crops)
+                if coarse_ready is not None:
+                    stream.wait_event(coarse_ready)
+                st = self._coarse_state
+                d = nets["fusion"].forward(ops, crops, rois[s:e], fdepth, ffeats, st["depth"], st["feats"], st["g2l"])
+                ops.copy_plane(d.unsqueeze(1), preds[s:e])
+        if use_aux:
+            main.wait_stream(self._aux_stream)
         if world > 1:
             from .dist import all_gather_shards
             preds = all_gather_shards(preds, n, world)

@@ -116,7 +116,8 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
         self.overlap_coarse = bool(config.get("overlap_coarse", True)) and _os.environ.get("PF_OVERLAP", "1") != "0"
         self.overlap_batches = bool(config.get("overlap_batches", True)) and _os.environ.get("PF_OVERLAP_BATCHES", "1") != "0"
         self._side_stream = None
-        self._aux_stream = None
+        self._aux_streams = []
+        self.n_streams = int(_os.environ.get("PF_STREAMS", config.get("n_streams", 2)))
         self._engine = None
         self._coarse_state = None
         if config.get("load_branch", False) and config.get("pretrain_model"):
@@ -261,13 +262,16 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
         # kernels of one batch (coarse pyramid levels L0..L2, B x 14x19 ... 56x74 maps) fill the gaps of the other
         use_aux = img.is_cuda and self.overlap_batches and (hi - lo) > process_num
         main = torch.cuda.current_stream() if img.is_cuda else None
+        streams = [main]
         if use_aux:
-            if self._aux_stream is None:
-                self._aux_stream = torch.cuda.Stream(device=dev)
-            self._aux_stream.wait_stream(main)
+            while len(self._aux_streams) < self.n_streams - 1:
+                self._aux_streams.append(torch.cuda.Stream(device=dev))
+            streams += self._aux_streams[:self.n_streams - 1]
+            for a in streams[1:]:
+                a.wait_stream(main)
         for bi, s in enumerate(range(lo, hi, process_num)):
             e = min(s + process_num, hi)
-            stream = self._aux_stream if (use_aux and bi % 2 == 1) else main
+            stream = streams[bi % len(streams)]
             ctx = torch.cuda.stream(stream) if img.is_cuda else _nullcontext()
             with ctx:
                 crops = ops.empty((e - s, 3, ph, pw), torch.float32, dev)
@@ -280,8 +284,8 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
                 st = self._coarse_state
                 d = nets["fusion"].forward(ops, crops, rois[s:e], fdepth, ffeats, st["depth"], st["feats"], st["g2l"])
                 ops.copy_plane(d.unsqueeze(1), preds[s:e])
-        if use_aux:
-            main.wait_stream(self._aux_stream)
+        for a in streams[1:]:
+            main.wait_stream(a)
         if world > 1:
             from .dist import all_gather_shards
             preds = all_gather_shards(preds, n, world)

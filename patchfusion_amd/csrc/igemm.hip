@@ -151,9 +151,40 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
   int ky = tap / p.KW, kx = tap - ky * p.KW;
 
   const unsigned smem_base = lds_addr(smem);
+  // GEMM fast path (1x1, K a multiple of the chunk): every source pointer just advances by 128 bytes per chunk
+  // (0 for the zero page) - no tap/mask/select arithmetic in the K loop
+  const bool fast = ntaps == 1 && (p.Cin % BK) == 0;
+  const char* a_cur[A_ITERS];
+  int a_inc[A_ITERS];
+#pragma unroll
+  for (int i = 0; i < A_ITERS; ++i) {
+    const bool ok = a_mask[i] & 1u;
+    a_cur[i] = ok ? a_ptr[i] + j * (VEC * (int)sizeof(T)) : zero;
+    a_inc[i] = ok ? 128 : 0;
+  }
+  const char* b_cur[B_ITERS];
+  int b_inc[B_ITERS];
+#pragma unroll
+  for (int i = 0; i < B_ITERS; ++i) {
+    b_cur[i] = b_ptr[i] ? b_ptr[i] : zero;
+    b_inc[i] = b_ptr[i] ? 128 : 0;
+  }
   auto issue = [&](int stage, int kc) {
     const unsigned As = smem_base + stage * STAGE + wave * (8 * 128);
     const unsigned Bs = As + A_BYTES;
+    if (fast) {
+#pragma unroll
+      for (int i = 0; i < A_ITERS; ++i) {
+        glds16(a_cur[i], As + i * (32 * 128));
+        a_cur[i] += a_inc[i];
+      }
+#pragma unroll
+      for (int i = 0; i < B_ITERS; ++i) {
+        glds16(b_cur[i], Bs + i * (32 * 128));
+        b_cur[i] += b_inc[i];
+      }
+      return;
+    }
     const long koff = ((long)(ky * p.W + kx) * p.x_ld + cv * VEC) * (long)sizeof(T);
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {

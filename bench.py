@@ -143,14 +143,18 @@ def gemm_sweep(dtype, dev):
     tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
     shapes = [("qkv", 8296, 1024, 3072, 1), ("proj", 8296, 1024, 1024, 1), ("fc1", 8296, 1024, 4096, 1), ("fc2", 8296, 4096, 1024, 1),
               ("up4_1", 8 * 224 * 296, 768, 768, 3), ("up4_2", 8 * 224 * 296, 768, 256, 3), ("c544_32", 8 * 392 * 518, 544, 32, 3),
-              ("c64_32", 8 * 392 * 518, 64, 32, 3), ("c256_256_L4", 8 * 224 * 296, 512, 256, 3)]
+              ("c64_32", 8 * 392 * 518, 64, 32, 3), ("c256_256_L4", 8 * 224 * 296, 512, 256, 3),
+              ("up3_768_L3", 8 * 112 * 148, 768, 768, 3), ("up2_768_L2", 8 * 56 * 74, 768, 768, 3), ("up1_768_L1", 8 * 28 * 37, 768, 768, 3),
+              ("c512_256_L2", 8 * 56 * 74, 512, 256, 3), ("c512_256_L1", 8 * 28 * 37, 512, 256, 3), ("c512_256_L0", 8 * 14 * 19, 512, 256, 3),
+              ("rcu256_L3", 8 * 112 * 148, 256, 256, 3)]
     for name, M, K, N, k in shapes:
         if k == 1:
             x = torch.randn(1, 1, M, K, device=dev).to(tdt)
             y = torch.empty(1, 1, M, N, device=dev, dtype=tdt)
             w = torch.randn(N, K) / K ** 0.5
         else:
-            hw = {8 * 224 * 296: (224, 296), 8 * 392 * 518: (392, 518)}[M]
+            hw = {8 * 224 * 296: (224, 296), 8 * 392 * 518: (392, 518), 8 * 112 * 148: (112, 148), 8 * 56 * 74: (56, 74),
+                  8 * 28 * 37: (28, 37), 8 * 14 * 19: (14, 19)}[M]
             x = torch.randn(8, hw[0], hw[1], K, device=dev).to(tdt)
             y = torch.empty(8, hw[0], hw[1], N, device=dev, dtype=tdt)
             w = torch.randn(N, K, 3, 3) / (9 * K) ** 0.5

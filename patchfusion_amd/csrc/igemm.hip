@@ -851,7 +851,10 @@ int dispatch(const pf_conv_params& p, hipStream_t st) {
   const long M = (long)p.B * p.OH * p.OW;
   if constexpr (sizeof(T) == 2) {
     if (g_force_small != 1 && g_force_small != 2 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.shuffle <= 1 &&
-        p.Cin % 32 == 0 && p.H >= 16 && p.W >= 32 && M >= 2048) {
+        p.Cin % 32 == 0 && p.H >= 16 && p.W >= 32 && M >= 2048 &&
+        // enough 16x32 tiles to fill the chip four times over; on small maps the padded tiles (e.g. 56x74 -> 64x96)
+        // and the few long-running blocks lose to the generic kernel (measured at L0..L3 of the pyramid)
+        (long)p.B * ((p.H + 15) / 16) * ((p.W + 31) / 32) * ((p.Cout + 127) / 128) >= 1024) {
       if (p.Cout <= 32) return p.relu_in ? launch_halo<1, 2, 1, true>(p, st) : launch_halo<1, 2, 1, false>(p, st);
       if (p.Cout <= 64) return p.relu_in ? launch_halo<1, 2, 2, true>(p, st) : launch_halo<1, 2, 2, false>(p, st);
       // channel tile: 192 when it wastes less than 128 (e.g. 544 -> 3x192 = 576 vs 5x128 = 640; 768 -> 4x192)

@@ -20,6 +20,13 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return (bf16_t)(u >> 16);
 }
 
+// two floats -> packed bf16x2 (round to nearest even) in ONE instruction; gfx950 has no clang builtin for it
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static constexpr int VEC = 4;  // elements per 16-byte vector
@@ -52,10 +59,10 @@ __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
 }
 __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
   uint4 a;
-  a.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-  a.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-  a.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
-  a.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+  a.x = cvt_pk_bf16(v[0], v[1]);
+  a.y = cvt_pk_bf16(v[2], v[3]);
+  a.z = cvt_pk_bf16(v[4], v[5]);
+  a.w = cvt_pk_bf16(v[6], v[7]);
   *reinterpret_cast<uint4*>(p) = a;
 }
 __device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
@@ -63,8 +70,8 @@ __device__ __forceinline__ void store4(float* p, float a, float b, float c, floa
 }
 __device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) {
   uint2 r;
-  r.x = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
-  r.y = (uint32_t)f2bf(c) | ((uint32_t)f2bf(d) << 16);
+  r.x = cvt_pk_bf16(a, b);
+  r.y = cvt_pk_bf16(c, d);
   *reinterpret_cast<uint2*>(p) = r;
 }
 __device__ __forceinline__ void load4(const float* p, float (&v)[4]) {

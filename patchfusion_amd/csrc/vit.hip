@@ -398,25 +398,32 @@ __global__ __launch_bounds__(256) void vit_attention32_kernel(const bf16_t* __re
       }
     }
     // ---- online softmax (query = lane & 31); register 4j+i of fragment f is key kt*64 + f*32 + 8j + 4fh + i ----
+    if (kt == ntiles - 1) {   // only the last tile can contain keys >= S (wave-uniform branch)
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 64 + f * 32 + 8 * (r >> 2) + 4 * fh + (r & 3);
+          if (key >= S) sc[f][r] = -INFINITY;
+        }
+    }
     float mx = -INFINITY;
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kt * 64 + f * 32 + 8 * (r >> 2) + 4 * fh + (r & 3);
-        if (key >= S) sc[f][r] = -INFINITY;
-        mx = fmaxf(mx, sc[f][r]);
-      }
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[f][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __expf(m_run - m_new);
+    // statistics in the base-2 domain: exp(x - m) = exp2(x*log2e - m*log2e); one fma + one v_exp_f32 per score
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float m_new = fmaxf(m_run, mx * LOG2E);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
     float psum = 0.f;
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pe = __expf(sc[f][r] - m_new);
+        const float pe = __builtin_amdgcn_exp2f(fmaf(sc[f][r], LOG2E, -m_new));
         sc[f][r] = pe;
         psum += pe;
       }
@@ -431,10 +438,10 @@ __global__ __launch_bounds__(256) void vit_attention32_kernel(const bf16_t* __re
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
         uint4 pb;
-        pb.x = (uint32_t)f2bf(sc[f][8 * jj + 0]) | ((uint32_t)f2bf(sc[f][8 * jj + 1]) << 16);
-        pb.y = (uint32_t)f2bf(sc[f][8 * jj + 2]) | ((uint32_t)f2bf(sc[f][8 * jj + 3]) << 16);
-        pb.z = (uint32_t)f2bf(sc[f][8 * jj + 4]) | ((uint32_t)f2bf(sc[f][8 * jj + 5]) << 16);
-        pb.w = (uint32_t)f2bf(sc[f][8 * jj + 6]) | ((uint32_t)f2bf(sc[f][8 * jj + 7]) << 16);
+        pb.x = cvt_pk_bf16(sc[f][8 * jj + 0], sc[f][8 * jj + 1]);
+        pb.y = cvt_pk_bf16(sc[f][8 * jj + 2], sc[f][8 * jj + 3]);
+        pb.z = cvt_pk_bf16(sc[f][8 * jj + 4], sc[f][8 * jj + 5]);
+        pb.w = cvt_pk_bf16(sc[f][8 * jj + 6], sc[f][8 * jj + 7]);
         // keys f*32+16jj+4fh..+3 -> logical slot 4f+2jj, 8-byte half fh ; keys +8 -> slot 4f+2jj+1, half fh
         const int s0 = 4 * f + 2 * jj;
 #pragma unroll

@@ -68,10 +68,12 @@ __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
 __device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
   *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
 }
+// (plain C++ packing here: the MFMA epilogues use store4, and an inline-asm pack makes hipcc spill the
+// accumulators of the register-tight 3x3 halo kernels - 832 B/lane of scratch, 2.5x slower end to end)
 __device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) {
   uint2 r;
-  r.x = cvt_pk_bf16(a, b);
-  r.y = cvt_pk_bf16(c, d);
+  r.x = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+  r.y = (uint32_t)f2bf(c) | ((uint32_t)f2bf(d) << 16);
   *reinterpret_cast<uint2*>(p) = r;
 }
 __device__ __forceinline__ void load4(const float* p, float (&v)[4]) {

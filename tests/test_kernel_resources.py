@@ -1,0 +1,26 @@
+"""Build-time guard: no gfx950 kernel of the MFMA family may use scratch (register spills).  The 3x3 halo
+kernels run at the 256-VGPR limit; an innocent-looking edit (e.g. an inline-asm bf16 pack in the epilogue)
+once made hipcc spill 832 B/lane and slowed the whole image pass 2.5x without failing any numerical test."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
+def test_mfma_kernels_have_no_scratch(tmp_path):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(ROOT, "patchfusion_amd", "csrc", "igemm.hip")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-c", src,
+                        "-o", str(tmp_path / "igemm.o"), "-Rpass-analysis=kernel-resource-usage"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    names = re.findall(r"Function Name: (\S+)", r.stderr)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+    assert len(names) == len(scratch) and len(names) >= 20
+    bad = {n: s for n, s in zip(names, scratch) if s > 0}
+    assert not bad, f"kernels with register spills: {bad}"

@@ -4,7 +4,7 @@ CPU (torch fp32, device-agnostic) restatement of the reference's tiled-inference
 ``PatchFusion.forward(mode='infer')`` -- as pure functions over a flat ``state_dict``.
 Every function cites the reference file:line (relative to /root/reference) it restates.
 
-Pinned against the reference itself: tests/test_oracle_vs_reference.py runs the reference's own
+Pinned against the reference itself: tests/test_oracle_golden.py / tests/test_baseline_cpu.py run the reference's own
 Python (oracle/ref_shim.py, only possible in the build container) on the same seeded weights and
 inputs and requires agreement to 1e-5; tests/golden/*.npz hold outputs of the reference generated
 by oracle/make_golden.py, so the check also runs where /root/reference is absent.
@@ -549,5 +549,43 @@ class Oracle:
             blur = torch.tensor(generatemask(tile_cfg["patch_raw_shape"]) + 1e-3, device=dev)
             avg.resize(tile_cfg["image_raw_shape"])
             for _ in range(int(cai_mode[1:]) // process_num):
+                avg = self.random_tile(img, blur, avg, tile_cfg, process_num)
+        return avg.average_map[None, None]
+
+
+class BaselineOracle(Oracle):
+    """BaselinePretrain.forward(mode='infer') -- baseline_pretrain.py:365-420: target='coarse' = the branch on
+    image_lr; target='fine' = tiles -> fine branch -> stitch (no coarse pass, no fusion).  NOTE r<N> makes N
+    random_tile calls here (:404-408), not N // process_num as in PatchFusion."""
+
+    def __init__(self, cfg_branch, process_shape, image_raw_shape, split, sd, target):
+        self.bcfg, self.ps, self.sd, self.target = cfg_branch, tuple(process_shape), sd, target
+        self.raw, self.split = tuple(image_raw_shape), tuple(split)
+        self.taps = None
+
+    def _predict(self, crops, bboxs, tile_cfg, process_num):
+        preds = [branch_forward(self.sd, self.target + "_branch.", crops[s:s + process_num], self.bcfg)[0]
+                 for s in range(0, crops.shape[0], process_num)]
+        return torch.cat(preds, dim=0)
+
+    @torch.no_grad()
+    def infer(self, image_lr, image_hr, cai_mode="m1", process_num=4, tile_cfg=None):
+        if self.target == "coarse":
+            return branch_forward(self.sd, "coarse_branch.", image_lr, self.bcfg)[0]
+        tile_cfg = prepare_tile_cfg(self.ps, self.raw, self.split) if tile_cfg is None else \
+            prepare_tile_cfg(self.ps, tile_cfg["image_raw_shape"], tile_cfg["patch_split_num"])
+        dev = image_hr.device
+        blur = torch.tensor(generatemask(self.ps) + 1e-3, device=dev)
+        img = image_hr[0]
+        avg = self.regular_tile([0, 0], [0, 0], img, True, blur, None, tile_cfg, process_num)
+        if cai_mode == "m2" or cai_mode[0] == "r":
+            hr, wr = tile_cfg["patch_raw_shape"]
+            for off, offp in (([0, wr // 2], [0, self.ps[1] // 2]), ([hr // 2, 0], [self.ps[0] // 2, 0]),
+                              ([hr // 2, wr // 2], [self.ps[0] // 2, self.ps[1] // 2])):
+                avg = self.regular_tile(off, offp, img, False, blur, avg, tile_cfg, process_num)
+        if cai_mode[0] == "r":
+            blur = torch.tensor(generatemask(tile_cfg["patch_raw_shape"]) + 1e-3, device=dev)
+            avg.resize(tile_cfg["image_raw_shape"])
+            for _ in range(int(cai_mode[1:])):
                 avg = self.random_tile(img, blur, avg, tile_cfg, process_num)
         return avg.average_map[None, None]

@@ -6,6 +6,7 @@ With mmengine installed (the reference environment) the class is registered into
 ``mmengine.registry.MODELS``; without it (this image) a minimal registry with the same
 ``register_module()`` / ``build(cfg)`` behaviour is provided so configs can still be built.
 """
+from .baseline import BaselinePretrain
 from .model import PatchFusion
 
 try:
@@ -45,10 +46,11 @@ class _NoLoss:
         pass
 
 
-try:
-    MODELS.register_module(name='PatchFusion', module=PatchFusion, force=True)
-except TypeError:  # pragma: no cover
-    MODELS.register_module(name='PatchFusion', module=PatchFusion)
+for _name, _cls in (('PatchFusion', PatchFusion), ('BaselinePretrain', BaselinePretrain)):
+    try:
+        MODELS.register_module(name=_name, module=_cls, force=True)
+    except TypeError:  # pragma: no cover
+        MODELS.register_module(name=_name, module=_cls)
 
 
 def build_model(cfg):

@@ -108,3 +108,25 @@ def test_vitl_patch_batch_vs_oracle_on_gpu():
             assert float(diff.max()) <= 0.5 * s and float(diff.mean()) <= 0.08 * s, (float(diff.max()), float(diff.mean()), s)
         del m
         torch.cuda.empty_cache()
+
+
+def test_baseline_pretrain_fine_and_coarse_vs_oracle():
+    """BaselinePretrain on the HIP engine: coarse branch and tiled fine branch (m2) vs oracle."""
+    from collections import OrderedDict
+    from patchfusion_amd.baseline import BaselinePretrain
+    from patchfusion_amd.config import zoe_branch_config
+    from patchfusion_amd.spec import branch_spec
+    ps, raw, split = (112, 154), (448, 616), (2, 2)
+    img = torch.rand(1, 3, *raw, generator=torch.Generator().manual_seed(1234))
+    for target, mode in (("coarse", "m1"), ("fine", "m2")):
+        bc = zoe_branch_config("vits", ps)
+        spec = OrderedDict()
+        branch_spec(spec, f"{target}_branch.", bc)
+        sd = synthetic_state_dict(spec, 0)
+        m = BaselinePretrain(bc, bc, dict(type="SILogLoss"), 1e-3, 80, raw, ps, split, target=target).eval()
+        m.load_state_dict(sd, strict=True)
+        m = m.cuda()
+        lr = m.resizer(img)
+        d, _ = m(mode="infer", image_lr=lr.cuda(), image_hr=img.cuda(), cai_mode=mode, process_num=2)
+        o = pf_oracle.BaselineOracle(bc, ps, raw, split, sd, target).infer(lr, img, mode, 2)
+        assert d.shape == o.shape and float((d.cpu() - o).abs().max()) < 2e-4, (target, float((d.cpu() - o).abs().max()))

@@ -725,12 +725,18 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params 
           if constexpr (RELU_IN) xf[fm] = relu_vec<T>(xf[fm]);
         }
 #endif
+#ifdef PF_HALO_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn)
 #pragma unroll
           for (int fm = 0; fm < FM; ++fm)
             acc[fn][fm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[fn]),
                                                                   __builtin_bit_cast(bf16x8, xf[fm]), acc[fn][fm], 0, 0, 0);
+#ifdef PF_HALO_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
       }
     }
     }

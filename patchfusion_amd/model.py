@@ -76,7 +76,10 @@ def _build_param_tree(root, spec):
             mod = mod._modules[p]
         leaf = parts[-1]
         if e.dtype.is_floating_point and e.kind not in ("bn_mean", "bn_var", "k_minus_1"):
-            mod.register_parameter(leaf, nn.Parameter(torch.zeros(e.shape, dtype=e.dtype), requires_grad=False))
+            # like the reference: branch parameters frozen (patchfusion.py:111-115), fusion-side parameters trainable
+            # (so that DistributedDataParallel(model) in tools/test.py:221 accepts the module)
+            frozen = name.startswith(("coarse_branch.", "fine_branch."))
+            mod.register_parameter(leaf, nn.Parameter(torch.zeros(e.shape, dtype=e.dtype), requires_grad=not frozen))
         else:
             mod.register_buffer(leaf, torch.zeros(e.shape, dtype=e.dtype))
 

@@ -37,7 +37,10 @@ def _worker(rank, world, port, mode, out_dir):
     m.load_state_dict(sd, strict=True)
     img = torch.rand(1, 3, *TINY[2], generator=torch.Generator().manual_seed(1234))
     random.seed(5621)
-    d, _ = m(mode="infer", image_lr=m.resizer(img), image_hr=img, cai_mode=mode, process_num=2)
+    # tools/test.py:221 wraps the model in DistributedDataParallel before Tester.run calls it
+    ddp = torch.nn.parallel.DistributedDataParallel(m)
+    with torch.no_grad():
+        d, _ = ddp(mode="infer", image_lr=m.resizer(img), image_hr=img, cai_mode=mode, process_num=2)
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), d.numpy())
     dist.destroy_process_group()
 

@@ -63,9 +63,9 @@ __device__ __forceinline__ void mma_half_f32(const uint4 (&wf)[FN], const uint4 
       }
 }
 
-// Measurement aid (PF_IGEMM_ABLATE=1: skip the DMA after the prologue; =2: skip ds_read+MFMA). Results are
-// wrong by construction in these modes; they are only used with pf_conv_timed to locate the bottleneck.
-__device__ int pf_ablate = 0;
+// Compile-time measurement variants (`make ablate`, never part of libpf_hip.so): PF_ABL_NODMA skips the DMA after
+// the prologue, PF_ABL_NOLDS the fragment ds_reads, PF_ABL_NOBAR the per-step barrier.  Results are wrong by
+// construction; they are only used with pf_conv_timed to locate the bottleneck of a kernel.
 
 // 256 bytes of zeros: source of every out-of-image / out-of-range 16-byte vector (conv padding, M/N tails)
 __device__ __attribute__((aligned(256))) unsigned int pf_zero_page[64];
@@ -218,15 +218,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
   const int a_row_off = (wm * WTM + fr) * 128;  // activations (pixels)
   const int b_row_off = (wn * WTN + fr) * 128;  // weights (channels)
 
-  const int ablate = pf_ablate;
   issue(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int kc = 0; kc < nk; ++kc) {
-    if (kc + 1 < nk && ablate != 1) issue((kc + 1) & 1, kc + 1);   // next chunk lands while this one is multiplied
+#ifndef PF_ABL_NODMA
+    if (kc + 1 < nk) issue((kc + 1) & 1, kc + 1);   // next chunk lands while this one is multiplied
+#endif
     const char* As = smem + (kc & 1) * STAGE;
     const char* Bs = As + A_BYTES;
-    if (ablate != 2)
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int slot = (((s << 2) | fg) ^ swz) << 4;
@@ -416,7 +416,6 @@ __global__ __launch_bounds__(512) void conv_igemm_big_kernel(const pf_conv_param
   const int a_row_off = (wm * 64 + fr) * 128;  // activations (pixels)
   const int b_row_off = (wn * 64 + fr) * 128;  // weights (channels)
 
-  const int ablate = pf_ablate;
   issue(0, 0);
   if (nk > 1) {
     issue(1, 1);
@@ -427,11 +426,10 @@ __global__ __launch_bounds__(512) void conv_igemm_big_kernel(const pf_conv_param
   __syncthreads();
   int st = 0;       // ring stage of chunk kc
   for (int kc = 0; kc < nk; ++kc) {
-    const bool more2 = kc + 2 < nk && ablate != 1;
+    const bool more2 = kc + 2 < nk;
     if (more2) issue(st >= 1 ? st - 1 : 2, kc + 2);   // (st + 2) % 3 : the stage consumed in iteration kc-1
     const char* As = smem + st * STAGE;
     const char* Bs = As + A_BYTES;
-    if (ablate != 2)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int slot = (((t << 1) | fh) ^ swz) << 4;
@@ -850,9 +848,6 @@ int dispatch(const pf_conv_params& p, hipStream_t st) {
   if (g_force_small < 0) {
     const char* e = getenv("PF_IGEMM_SMALL");
     g_force_small = e ? atoi(e) : 0;   // 1: 4-wave kernel everywhere; 2: no halo kernel (big/small only)
-    const char* a = getenv("PF_IGEMM_ABLATE");
-    int av = a ? atoi(a) : 0;
-    hipMemcpyToSymbol(HIP_SYMBOL(pf_ablate), &av, sizeof(int));
   }
   const long M = (long)p.B * p.OH * p.OW;
   if constexpr (sizeof(T) == 2) {

@@ -549,6 +549,48 @@ int launch_big(const pf_conv_params& p, hipStream_t st) {
 // start of step g every wave issues a third of the NEXT chunk's halo and the weights of step g+1, which have
 // the whole step (72 MFMAs per wave) to land before the single vmcnt(0)+barrier that ends it.
 // -------------------------------------------------------------------------------------------------
+// ---- hand-counted LDS reads (see the 12-fragment branch of conv3x3_halo_kernel).  An asm ds_read is invisible to
+// hipcc's s_waitcnt bookkeeping; lds_wait<N> names the registers whose data it guarantees so that no consumer is
+// scheduled above it.  (native vector type: HIP's uint4 is a struct and cannot be a tied asm register operand) ----
+typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
+__device__ __forceinline__ u32x4 lds_read16_asm(unsigned addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read16_asm_off(unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field is 16 bits");
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(u32x4& a) {
+  u32x4 ta = a;
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ta) : "n"(N));
+  a = ta;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
+  u32x4 ta = a, tb = b, tc = c, td = d;
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(ta), "+v"(tb), "+v"(tc), "+v"(td) : "n"(N));
+  a = ta; b = tb; c = tc; d = td;
+}
+
+template <int N>
+__device__ __forceinline__ void lds_wait(u32x4& a, u32x4& b, u32x4& c, u32x4& d, u32x4& e, u32x4& f) {
+  u32x4 ta = a, tb = b, tc = c, td = d, te = e, tf = f;
+  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(ta), "+v"(tb), "+v"(tc), "+v"(td), "+v"(te), "+v"(tf) : "n"(N));
+  a = ta; b = tb; c = tc; d = td; e = te; f = tf;
+}
+
+#ifdef PF_HALO_NOROLL     // A/B builds only: leave the fragment reads of the halo kernels to hipcc's scheduler
+constexpr bool kHaloRoll = false;
+#else
+constexpr bool kHaloRoll = true;
+#endif
+
 template <int WN, int FM, int FN, bool RELU_IN>
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params p) {
   using T = bf16_t;
@@ -565,7 +607,10 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params 
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
+  // wave -> (pixel-row group wm, channel group wn).  Waves w and w+4 share a SIMD; for WN = 2 they get different
+  // channel halves and row groups two apart (measured +1 % over wm = wave / 2, wn = wave % 2 on the 544->544 layer).
+  const int wm = WN == 2 ? (wave < 4 ? wave : ((wave + 2) & 3)) : wave / WN;
+  const int wn = WN == 2 ? (wave >> 2) : wave % WN;
   const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
   const int nt = (p.Cout + BN - 1) / BN;
   const int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
@@ -647,6 +692,13 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params 
     w_swz[fn] = (row >> 2) & 3;
   }
 
+  unsigned roll_w[2];                        // (hand-scheduled 12-fragment path) weight read address per k-half, ring slot 0
+  {
+    const int o0 = (fh ^ ((fr >> 2) & 3)) << 4;
+    roll_w[0] = smem_base + LDS_W0 + (wn * (32 * FN) + fr) * 64 + o0;
+    roll_w[1] = smem_base + LDS_W0 + (wn * (32 * FN) + fr) * 64 + (o0 ^ 32);
+  }
+
   // ---- prologue: whole halo of chunk 0 and the weight rows of step 0 ----
   if (loader) {
     issue_a(0, 0);
@@ -669,7 +721,54 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params 
     // ---- multiply filter row ky (three taps) of this chunk ----
     const char* Ab = smem + (chunk & 1) * A_BUF;
     const char* Wb = smem + LDS_W0 + (g & 1) * W_STAGE;
-    if constexpr (FN * FM <= 8) {
+    if constexpr (kHaloRoll && FN == 2 && FM == 4) {
+      // 8-fragment tile (128 accumulator registers): room for two complete fragment sets.  Same hand-counted asm
+      // reads as the 12-fragment path below: the six reads of sub-step u+1 are issued BEFORE the eight MFMAs of
+      // sub-step u (hipcc, left to itself, sinks them next to their first use and waits lgkmcnt(0) in between).
+      const unsigned a_lds = smem_base + (chunk & 1) * A_BUF;
+      u32x4 wf[2][FN], xf[2][FM];
+      auto rd_all = [&](auto uc) {
+        constexpr int u = decltype(uc)::value, kx = u >> 1, t = u & 1, bsel = u & 1;
+        wf[bsel][0] = lds_read16_asm_off<kx * W_TILE>(roll_w[t]);
+        wf[bsel][1] = lds_read16_asm_off<kx * W_TILE + 2048>(roll_w[t]);
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+          const int row = fr + (FM * wm + fm + ky) * HW_ + kx;
+          xf[bsel][fm] = lds_read16_asm(a_lds + row * 64 + ((((t << 1) | fh) ^ ((row >> 2) & 3)) << 4));
+        }
+      };
+      auto substep = [&](auto uc) {
+        constexpr int u = decltype(uc)::value, c = u & 1;
+        constexpr bool more = u + 1 < 6;
+        if constexpr (more) {
+          rd_all(std::integral_constant<int, (more ? u + 1 : u)>{});
+          lds_wait<6>(wf[c][0], wf[c][1], xf[c][0], xf[c][1], xf[c][2], xf[c][3]);
+        } else {
+          lds_wait<0>(wf[c][0], wf[c][1], xf[c][0], xf[c][1], xf[c][2], xf[c][3]);
+        }
+        if constexpr (RELU_IN) {
+#pragma unroll
+          for (int fm = 0; fm < FM; ++fm) {
+            uint4 v = __builtin_bit_cast(uint4, xf[c][fm]);
+            xf[c][fm] = __builtin_bit_cast(u32x4, relu_vec<T>(v));
+          }
+        }
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+          for (int fm = 0; fm < FM; ++fm)
+            acc[fn][fm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[c][fn]),
+                                                                  __builtin_bit_cast(bf16x8, xf[c][fm]), acc[fn][fm], 0, 0, 0);
+      };
+      rd_all(std::integral_constant<int, 0>{});
+      substep(std::integral_constant<int, 0>{}); substep(std::integral_constant<int, 1>{});
+      substep(std::integral_constant<int, 2>{}); substep(std::integral_constant<int, 3>{});
+      substep(std::integral_constant<int, 4>{}); substep(std::integral_constant<int, 5>{});
+      {
+        const int d = (g & 1) ? -W_STAGE : W_STAGE;
+        roll_w[0] += d; roll_w[1] += d;
+      }
+    } else if constexpr (FN * FM <= 8) {
       // software-pipelined fragment reads (enough registers when the accumulator tile is <= 8 fragments):
       // the ds_reads of sub-step u+1 = (kx, t) are in flight while the MFMAs of sub-step u execute
       uint4 wf[2][FN], xf[2][FM];
@@ -697,6 +796,71 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params 
           for (int fm = 0; fm < FM; ++fm)
             acc[fn][fm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[u & 1][fn]),
                                                                   __builtin_bit_cast(bf16x8, xf[u & 1][fm]), acc[fn][fm], 0, 0, 0);
+      }
+    } else if constexpr (kHaloRoll && !RELU_IN) {
+      // 12-fragment tile: 192 of the wave's 256 registers hold accumulators, so a second fragment set does not fit,
+      // and hipcc sinks every ds_read next to its first use (`ds_read; s_waitcnt lgkmcnt(0); mfma`: the full LDS
+      // latency exposed ~20x per step).  Hand-placed rolling prefetch instead: LDS reads are inline asm (invisible to
+      // hipcc's waitcnt bookkeeping), the pixel fragment is the OUTER loop, x[fm] is dead after its FN MFMAs and the
+      // read of the NEXT sub-step's x[fm] goes into the same registers right there; the next w[fn] is read right after
+      // the last MFMA of the sub-step that uses w[fn].  LDS returns in order, so each wait is a fixed count of the
+      // younger reads that may still be in flight; every wait names the registers it releases so that the MFMAs
+      // stay below it.  Weight addresses: the swizzle term (row>>2)&3 of row = 96 wn + 32 fn + fr is (fr>>2)&3 for
+      // every fn, so ONE register per k-half (roll_w[t], advanced between the two ring slots at the end of the step)
+      // addresses all of them through the 16-bit offset field (tap kx: + kx * W_TILE, fragment fn: + 2048 fn).
+      static_assert(FN == 3 && FM == 4, "issue order and wait counts below are for the 3x4 fragment tile");
+      const unsigned a_lds = smem_base + (chunk & 1) * A_BUF;
+      u32x4 wf[FN], xf[FM];
+      auto rd_x = [&](auto uc, auto fmc) {
+        constexpr int u = decltype(uc)::value, fm = decltype(fmc)::value;
+        constexpr int kx = u >> 1, t = u & 1;
+        const int row = fr + (FM * wm + fm + ky) * HW_ + kx;        // uniform part lives in SGPRs
+        const unsigned ad = a_lds + row * 64 + ((((t << 1) | fh) ^ ((row >> 2) & 3)) << 4);
+        xf[fm] = lds_read16_asm(ad);
+      };
+      auto rd_w = [&](auto uc, auto fnc) {
+        constexpr int u = decltype(uc)::value, fn = decltype(fnc)::value;
+        wf[fn] = lds_read16_asm_off<(u >> 1) * W_TILE + fn * 2048>(roll_w[u & 1]);
+      };
+      auto mma = [&](int fn, int fm) {
+        acc[fn][fm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[fn]),
+                                                              __builtin_bit_cast(bf16x8, xf[fm]), acc[fn][fm], 0, 0, 0);
+      };
+      using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+      // LDS issue order per sub-step: x0 x1 x2 | w0 w1 w2 | x3
+      rd_x(I0{}, I0{}); rd_x(I0{}, I1{}); rd_x(I0{}, I2{});
+      rd_w(I0{}, I0{}); rd_w(I0{}, I1{}); rd_w(I0{}, I2{});
+      rd_x(I0{}, I3{});
+      auto substep = [&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        constexpr bool more = u + 1 < 6;
+        using UN = std::integral_constant<int, (more ? u + 1 : u)>;
+        // younger than w0: w1 w2 x3 -> 3, than w1 -> 2, than w2 -> 1 (x0..x2 are older than the w's)
+        lds_wait<3>(wf[0], xf[0], xf[1], xf[2]);
+        mma(0, 0);
+        lds_wait<2>(wf[1]);
+        mma(1, 0);
+        lds_wait<1>(wf[2]);
+        mma(2, 0);
+        if constexpr (more) rd_x(UN{}, I0{});
+        mma(0, 1); mma(1, 1); mma(2, 1);
+        if constexpr (more) rd_x(UN{}, I1{});
+        mma(0, 2); mma(1, 2); mma(2, 2);
+        if constexpr (more) rd_x(UN{}, I2{});
+        if constexpr (more) lds_wait<3>(xf[3]); else lds_wait<0>(xf[3]);   // younger than x3: the three x reads just issued
+        mma(0, 3);
+        if constexpr (more) rd_w(UN{}, I0{});
+        mma(1, 3);
+        if constexpr (more) rd_w(UN{}, I1{});
+        mma(2, 3);
+        if constexpr (more) { rd_w(UN{}, I2{}); rd_x(UN{}, I3{}); }
+      };
+      substep(I0{}); substep(I1{}); substep(I2{}); substep(I3{});
+      substep(std::integral_constant<int, 4>{}); substep(std::integral_constant<int, 5>{});
+      {
+        const int d = (g & 1) ? -W_STAGE : W_STAGE;                        // other ring slot for the next step
+        roll_w[0] += d; roll_w[1] += d;
       }
     } else {
 #pragma unroll
@@ -843,6 +1007,11 @@ int g_force_small = -1;   // PF_IGEMM_SMALL=1 forces the 4-wave kernel everywher
 // difference between 2 half-empty rounds of 256x128 tiles and 1 full round of 128x96 tiles.
 struct TileCfg { int bm, bn, occ; float eff; int id; };
 
+static bool force_halo() {
+  const char* e = getenv("PF_HALO_FORCE");
+  return e && e[0] == '1';
+}
+
 template <typename T>
 int dispatch(const pf_conv_params& p, hipStream_t st) {
   if (g_force_small < 0) {
@@ -852,10 +1021,11 @@ int dispatch(const pf_conv_params& p, hipStream_t st) {
   const long M = (long)p.B * p.OH * p.OW;
   if constexpr (sizeof(T) == 2) {
     if (g_force_small != 1 && g_force_small != 2 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.shuffle <= 1 &&
-        p.Cin % 32 == 0 && p.H >= 16 && p.W >= 32 && M >= 2048 &&
+        p.Cin % 32 == 0 && p.H >= 16 && p.W >= 32 &&
         // enough 16x32 tiles to fill the chip four times over; on small maps the padded tiles (e.g. 56x74 -> 64x96)
-        // and the few long-running blocks lose to the generic kernel (measured at L0..L3 of the pyramid)
-        (long)p.B * ((p.H + 15) / 16) * ((p.W + 31) / 32) * ((p.Cout + 127) / 128) >= 1024) {
+        // and the few long-running blocks lose to the generic kernel (measured at L0..L3 of the pyramid).
+        // PF_HALO_FORCE=1 (read per call; unit tests) routes small shapes here too.
+        (force_halo() || (M >= 2048 && (long)p.B * ((p.H + 15) / 16) * ((p.W + 31) / 32) * ((p.Cout + 127) / 128) >= 1024))) {
       if (p.Cout <= 32) return p.relu_in ? launch_halo<1, 2, 1, true>(p, st) : launch_halo<1, 2, 1, false>(p, st);
       if (p.Cout <= 64) return p.relu_in ? launch_halo<1, 2, 2, true>(p, st) : launch_halo<1, 2, 2, false>(p, st);
       // channel tile: 192 when it wastes less than 128 (e.g. 544 -> 3x192 = 576 vs 5x128 = 640; 768 -> 4x192)

@@ -124,16 +124,44 @@ def conv_big_3x3_n160(dt):
     return _conv_case(dt, 3, 30, 41, 160, 160, 3, pad=1, act="relu", seed=13)
 
 
+# ---- 3x3 tap-reuse (halo) kernel variants; PF_HALO_FORCE=1 routes these small shapes to it (bf16 only; the fp32
+# ---- run of the same case exercises the generic kernel).  Shapes hang over the tile edges on purpose: rows
+# ---- (H % 16 != 0 -> idle wave rows), columns (W % 32 != 0) and channels (Cout % BN != 0 -> skipped fragments).
+def _halo_case(*a, **k):
+    import os
+    old = os.environ.get("PF_HALO_FORCE")
+    os.environ["PF_HALO_FORCE"] = "1"
+    try:
+        return _conv_case(*a, **k)
+    finally:
+        if old is None:
+            del os.environ["PF_HALO_FORCE"]
+        else:
+            os.environ["PF_HALO_FORCE"] = old
+
+
 def conv_halo_n32(dt):
-    return _conv_case(dt, 2, 40, 52, 64, 32, 3, pad=1, act="relu", y_extra=16, seed=21)
+    return _halo_case(dt, 2, 40, 52, 64, 32, 3, pad=1, act="relu", y_extra=16, seed=21)
 
 
 def conv_halo_n64_res(dt):
-    return _conv_case(dt, 2, 33, 67, 160, 64, 3, pad=1, relu_in=True, res=True, seed=22)
+    return _halo_case(dt, 2, 33, 67, 160, 64, 3, pad=1, relu_in=True, res=True, seed=22)
 
 
 def conv_halo_n32_cin544(dt):
-    return _conv_case(dt, 1, 50, 70, 544, 32, 3, pad=1, act="relu", seed=23)
+    return _halo_case(dt, 1, 50, 70, 544, 32, 3, pad=1, act="relu", seed=23)
+
+
+def conv_halo_bn192_n544(dt):      # <2,4,3>: 544 = 192 + 192 + 160 (one skipped fragment), 40 rows = 2.5 tiles
+    return _halo_case(dt, 1, 40, 70, 64, 544, 3, pad=1, act="relu", seed=24)
+
+
+def conv_halo_bn128_n224(dt):      # <2,4,2>: 224 = 128 + 96 (one skipped fragment), 21 rows (partial + idle wave rows)
+    return _halo_case(dt, 2, 21, 45, 96, 224, 3, pad=1, relu_in=True, res=True, res2=True, seed=25)
+
+
+def conv_halo_bn192_n160(dt):      # <2,4,3> with a single 192 tile: second channel half keeps 2 of 3 fragments
+    return _halo_case(dt, 1, 24, 31, 32, 160, 3, pad=1, seed=26)
 
 
 def conv_big_stride2(dt):
@@ -387,6 +415,7 @@ CHECKS = {
     "conv_big_3x3_rcu": conv_big_3x3_rcu, "conv_big_3x3_n544_views": conv_big_3x3_n544_views,
     "conv_big_3x3_n160": conv_big_3x3_n160, "conv_big_stride2": conv_big_stride2,
     "conv_halo_n32": conv_halo_n32, "conv_halo_n64_res": conv_halo_n64_res, "conv_halo_n32_cin544": conv_halo_n32_cin544,
+    "conv_halo_bn192_n544": conv_halo_bn192_n544, "conv_halo_bn128_n224": conv_halo_bn128_n224, "conv_halo_bn192_n160": conv_halo_bn192_n160,
     "conv_big_gemm_scale_inplace": conv_big_gemm_scale_inplace, "conv_big_gemm_gelu_k1024": conv_big_gemm_gelu_k1024,
     "conv_big_transpose": conv_big_transpose,
     "conv_transpose": conv_transpose, "patch_embed_tokens": patch_embed_tokens, "layernorm": layernorm,

@@ -16,7 +16,7 @@ def test_mfma_kernels_have_no_scratch(tmp_path):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     src = os.path.join(ROOT, "patchfusion_amd", "csrc", "igemm.hip")
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-c", src,
-                        "-o", str(tmp_path / "igemm.o"), "-Rpass-analysis=kernel-resource-usage"],
+                        "-o", str(tmp_path / "igemm.o"), "-Rpass-analysis=kernel-resource-usage", "-save-temps=obj"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     names = re.findall(r"Function Name: (\S+)", r.stderr)
@@ -24,3 +24,13 @@ def test_mfma_kernels_have_no_scratch(tmp_path):
     assert len(names) == len(scratch) and len(names) >= 20
     bad = {n: s for n, s in zip(names, scratch) if s > 0}
     assert not bad, f"kernels with register spills: {bad}"
+
+    # hand-counted LDS reads (inline-asm ds_read + s_waitcnt lgkmcnt(N) in the halo kernels): no instruction may touch
+    # a destination register before the wait that releases it (tools/asm_lds_audit.py simulates the in-order queue)
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import asm_lds_audit
+    listing = [f for f in os.listdir(tmp_path) if f.endswith("gfx950.s")]
+    assert listing, os.listdir(tmp_path)
+    n, viol = asm_lds_audit.audit(str(tmp_path / listing[0]))
+    assert n >= 8 and not viol, viol[:5]

@@ -145,6 +145,43 @@ int pf_stitch_update(float* avg, float* count, int MH, int MW, const float* dept
 int pf_resize_nearest_f32(const float* x, int H, int W, float* y, int OH, int OW, void* stream);
 int pf_resize_bilinear_f32(const float* x, int H, int W, float* y, int OH, int OW, void* stream);
 
+/* ==== input / output side of the path: HBM-bound byte/float streaming ==== */
+
+/* estimator/datasets/general_dataset.py:22-47 read_image(): decoded uint8 HWC RGB -> `img / 255.0` (float64) ->
+ * F.interpolate(bicubic, align_corners=True) to image_raw_shape -> float32 CHW planes (`to_tensor(...).float()`, :201).
+ * Evaluated in double like the reference; H == OH && W == OW is the exact conversion; reverse_channels = the
+ * `[:, :, ::-1]` of the 'u4k' raw-file branch (:24-25). dst is [3][OH][OW]. */
+int pf_u8_bicubic_to_f32(const uint8_t* src, int H, int W, int reverse_channels, float* dst, int OH, int OW, void* stream);
+
+/* estimator/utils/color.py:127-128: np.percentile(value[mask], q0 / q1) with mask = (value != invalid_val) when
+ * use_invalid.  Exact order statistics by a three-level radix select on order-preserving integer keys, linear
+ * interpolation as numpy 1.24 (the reference's pinned version): index and weight in double, difference in float32.
+ * out2 = {percentile q0, percentile q1} (device, float32; NaN when no valid sample).  `workspace`: device buffer of
+ * pf_percentile_workspace_bytes() bytes, contents irrelevant on entry. */
+int pf_percentile_workspace_bytes(void);
+int pf_percentiles_f32(const float* x, long n, float invalid_val, int use_invalid, double q0, double q1, float* out2,
+                       void* workspace, void* stream);
+
+/* estimator/utils/color.py:130-150 + matplotlib Colormap.__call__(bytes=True): x = (v - vmin)/(vmax - vmin) in float32
+ * (v*0 when vmin == vmax), index = trunc(x*N) with matplotlib's under / over / bad rules; lut_rgba has N+3 RGBA rows
+ * (N colours, under, over, bad), already `(lut*255).astype(uint8)`; vmin_vmax is a device float[2] (e.g. the output of
+ * pf_percentiles_f32); invalid pixels (v == invalid_val) get background_rgba (R | G<<8 | B<<16 | A<<24). out: [n][4]. */
+int pf_colorize_f32(const float* depth, long n, const float* vmin_vmax, const uint8_t* lut_rgba, int N, float invalid_val,
+                    int use_invalid, uint32_t background_rgba, uint8_t* out_rgba, void* stream);
+
+/* estimator/tester/tester.py:75: (depth * 256).astype('uint16') (float32 product, truncation; clamped to [0, 65535]) */
+int pf_depth_to_u16(const float* depth, long n, float scale, uint16_t* out, void* stream);
+
+/* estimator/utils/metric.py:87-148 compute_metrics (+ compute_errors :10-52, soft_edge_error :66-71) as one masked
+ * reduction over the ground-truth grid [H][W]: pred [ph][pw] is resized on the fly (bilinear, align_corners=False)
+ * when the grids differ, clamped to [min_depth, max_depth] (inf -> max, nan -> min); mask = min < gt < max inside the
+ * evaluation rectangle rows [crop_y0, crop_y1) x cols [crop_x0, crop_x1) (garg / eigen crops; whole image = 0,H,0,W);
+ * edges (or NULL) = disp_gt_edges, non-zero = boundary pixel.  Terms in float32 like numpy, sums in double:
+ * out13 = n, #(thresh<1.25), #(<1.25^2), #(<1.25^3), S|gt-p|/gt, S(gt-p)^2/gt, S(gt-p)^2, S(ln gt - ln p)^2,
+ *         S(ln p - ln gt), S(ln p - ln gt)^2, S|log10 gt - log10 p|, S soft-edge error, #(mask & edges)   (device) */
+int pf_depth_metrics(const float* gt, int H, int W, const float* pred, int ph, int pw, const float* edges, float min_depth,
+                     float max_depth, int crop_y0, int crop_y1, int crop_x0, int crop_x1, double* out13, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,7 +52,14 @@ SIGNATURES = {
     "pf_stitch_update": [vp, vp, ci, ci, vp, ci, ci, vp, ci, ci, ci, ci, vp],
     "pf_resize_nearest_f32": [vp, ci, ci, vp, ci, ci, vp],
     "pf_resize_bilinear_f32": [vp, ci, ci, vp, ci, ci, vp],
+    # input / output side (io.hip)
+    "pf_u8_bicubic_to_f32": [vp, ci, ci, ci, vp, ci, ci, vp],
+    "pf_percentiles_f32": [vp, cl, cf, ci, C.c_double, C.c_double, vp, vp, vp],
+    "pf_colorize_f32": [vp, cl, vp, vp, ci, cf, ci, C.c_uint32, vp, vp],
+    "pf_depth_to_u16": [vp, cl, cf, vp, vp],
+    "pf_depth_metrics": [vp, ci, ci, vp, ci, ci, vp, cf, cf, ci, ci, ci, ci, vp, vp],
 }
+NON_STATUS = ("pf_last_error", "pf_version", "pf_percentile_workspace_bytes")   # entry points that do not return a status
 
 _lib = None
 
@@ -75,6 +82,8 @@ def load():
     lib.pf_last_error.argtypes = []
     lib.pf_version.restype = ci
     lib.pf_version.argtypes = []
+    lib.pf_percentile_workspace_bytes.restype = ci
+    lib.pf_percentile_workspace_bytes.argtypes = []
     _lib = lib
     return lib
 

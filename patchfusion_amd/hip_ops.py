@@ -291,5 +291,53 @@ class HipOps:
     def resize_bilinear_f32(x, y):
         check(_L.pf_resize_bilinear_f32(_p(x), x.shape[0], x.shape[1], _p(y), y.shape[0], y.shape[1], _stream()), "pf_resize_bilinear_f32")
 
+    # ---------------- input / output side (io.hip) ----------------
+    @staticmethod
+    def u8_bicubic_to_f32(img_u8, out, reverse_channels=False):
+        """img_u8 [H,W,3] uint8 -> out [3,OH,OW] float32 (value/255, bicubic align_corners=True evaluated in double)."""
+        assert img_u8.dtype == torch.uint8 and img_u8.dim() == 3 and img_u8.shape[2] == 3 and img_u8.is_contiguous()
+        assert out.dtype == torch.float32 and out.dim() == 3 and out.shape[0] == 3 and out.is_contiguous()
+        check(_L.pf_u8_bicubic_to_f32(_p(img_u8), img_u8.shape[0], img_u8.shape[1], int(bool(reverse_channels)), _p(out), out.shape[1],
+                                      out.shape[2], _stream()), "pf_u8_bicubic_to_f32")
+        return out
+
+    @staticmethod
+    def percentiles(x, q0, q1, invalid_val=None, out=None):
+        """Exact np.percentile(x[x != invalid_val], [q0, q1]) (linear) of a float32 tensor -> device float32 [2]."""
+        assert x.dtype == torch.float32 and x.is_contiguous()
+        ws = torch.empty(_L.pf_percentile_workspace_bytes(), dtype=torch.uint8, device=x.device)
+        out = torch.empty(2, dtype=torch.float32, device=x.device) if out is None else out
+        check(_L.pf_percentiles_f32(_p(x), x.numel(), float(invalid_val if invalid_val is not None else 0.0), int(invalid_val is not None),
+                                    float(q0), float(q1), _p(out), _p(ws), _stream()), "pf_percentiles_f32")
+        return out
+
+    @staticmethod
+    def colorize(depth, vmin_vmax, lut_rgba, N, invalid_val, background_rgba, out):
+        assert depth.dtype == torch.float32 and depth.is_contiguous() and vmin_vmax.dtype == torch.float32 and vmin_vmax.numel() == 2
+        assert lut_rgba.dtype == torch.uint8 and lut_rgba.shape == (N + 3, 4) and lut_rgba.is_contiguous()
+        assert out.dtype == torch.uint8 and out.numel() == depth.numel() * 4 and out.is_contiguous()
+        r, g, b, a = (int(v) & 255 for v in background_rgba)
+        check(_L.pf_colorize_f32(_p(depth), depth.numel(), _p(vmin_vmax), _p(lut_rgba), int(N), float(invalid_val if invalid_val is not None else 0.0),
+                                 int(invalid_val is not None), r | (g << 8) | (b << 16) | (a << 24), _p(out), _stream()), "pf_colorize_f32")
+        return out
+
+    @staticmethod
+    def depth_to_u16(depth, out, scale=256.0):
+        assert depth.dtype == torch.float32 and depth.is_contiguous() and out.dtype == torch.uint16 and out.numel() == depth.numel()
+        check(_L.pf_depth_to_u16(_p(depth), depth.numel(), float(scale), _p(out), _stream()), "pf_depth_to_u16")
+        return out
+
+    @staticmethod
+    def depth_metrics(gt, pred, edges, min_depth, max_depth, crop, out13):
+        """gt [H,W], pred [h,w] float32, edges [H,W] float32 or None, crop = (y0, y1, x0, x1) -> out13 (device float64 [13])."""
+        assert gt.dtype == torch.float32 and pred.dtype == torch.float32 and gt.dim() == 2 and pred.dim() == 2
+        assert gt.is_contiguous() and pred.is_contiguous() and out13.dtype == torch.float64 and out13.numel() == 13
+        if edges is not None:
+            assert edges.dtype == torch.float32 and edges.shape == gt.shape and edges.is_contiguous()
+        y0, y1, x0, x1 = (int(v) for v in crop)
+        check(_L.pf_depth_metrics(_p(gt), gt.shape[0], gt.shape[1], _p(pred), pred.shape[0], pred.shape[1], _p(edges), float(min_depth),
+                                  float(max_depth), y0, y1, x0, x1, _p(out13), _stream()), "pf_depth_metrics")
+        return out13
+
 
 ops = HipOps()

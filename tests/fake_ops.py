@@ -259,5 +259,77 @@ class FakeOps:
     def resize_bilinear_f32(x, y):
         y[:] = F.interpolate(x[None, None], size=tuple(y.shape), mode="bilinear", align_corners=True)[0, 0]
 
+    # ---------------- input / output side (reference semantics through torch / the oracle) ----------------
+    @staticmethod
+    def u8_bicubic_to_f32(img_u8, out, reverse_channels=False):
+        x = (img_u8.double() / 255.0).permute(2, 0, 1)[None]
+        if tuple(x.shape[-2:]) != tuple(out.shape[-2:]):
+            x = F.interpolate(x, tuple(out.shape[-2:]), mode="bicubic", align_corners=True)
+        x = x[0].float()
+        out[:] = x.flip(0) if reverse_channels else x
+        return out
+
+    @staticmethod
+    def percentiles(x, q0, q1, invalid_val=None, out=None):
+        from oracle import io_oracle
+        v = x.cpu().numpy().ravel()
+        if invalid_val is not None:
+            v = v[v != invalid_val]
+        r = torch.tensor([float(io_oracle.percentile_linear(v, q0)), float(io_oracle.percentile_linear(v, q1))], dtype=torch.float32)
+        if out is not None:
+            out[:] = r
+            return out
+        return r.to(x.device)
+
+    @staticmethod
+    def colorize(depth, vmin_vmax, lut_rgba, N, invalid_val, background_rgba, out):
+        import numpy as np
+        from oracle import io_oracle
+        v = depth.cpu().numpy().copy()
+        inv = (v == invalid_val) if invalid_val is not None else np.zeros(v.shape, bool)
+        vmin, vmax = (np.float32(t) for t in vmin_vmax.tolist())
+        v = (v - vmin) / (vmax - vmin) if vmin != vmax else v * np.float32(0)
+        v[inv] = np.nan
+        img = io_oracle.colormap_bytes(v, lut_rgba.cpu().numpy(), N)
+        img[inv] = background_rgba
+        out.view(depth.shape + (4,))[:] = torch.from_numpy(img)
+        return out
+
+    @staticmethod
+    def depth_to_u16(depth, out, scale=256.0):
+        out[:] = torch.from_numpy((depth.cpu().numpy() * depth.cpu().numpy().dtype.type(scale)).astype("uint16"))
+        return out
+
+    @staticmethod
+    def depth_metrics(gt, pred, edges, min_depth, max_depth, crop, out13):
+        import numpy as np
+        from oracle import io_oracle
+        if gt.shape != pred.shape:
+            pred = F.interpolate(pred[None, None], tuple(gt.shape), mode="bilinear", align_corners=False)[0, 0]
+        p = pred.cpu().numpy().copy()
+        p[p < min_depth] = min_depth
+        p[p > max_depth] = max_depth
+        p[np.isinf(p)] = max_depth
+        p[np.isnan(p)] = min_depth
+        g = gt.cpu().numpy()
+        m = np.logical_and(g > min_depth, g < max_depth)
+        em = np.zeros(m.shape, bool)
+        em[crop[0]:crop[1], crop[2]:crop[3]] = True
+        m &= em
+        gv, pv = g[m].astype(np.float32), p[m].astype(np.float32)
+        th = np.maximum(gv / pv, pv / gv)
+        lg, lp = np.log(gv), np.log(pv)
+        f = np.float64
+        s = [f(m.sum()), f((th < 1.25).sum()), f((th < 1.25 ** 2).sum()), f((th < 1.25 ** 3).sum()), (np.abs(gv - pv) / gv).astype(f).sum(),
+             (((gv - pv) ** 2) / gv).astype(f).sum(), ((gv - pv) ** 2).astype(f).sum(), ((lg - lp) ** 2).astype(f).sum(),
+             (lp - lg).astype(f).sum(), ((lp - lg) ** 2).astype(f).sum(), np.abs(np.log10(gv) - np.log10(pv)).astype(f).sum(), 0.0, 0.0]
+        if edges is not None:
+            me = np.logical_and(m, edges.cpu().numpy() != 0)
+            if me.sum():
+                s[11] = io_oracle.soft_edge_error(p, g)[me].astype(f).sum()
+                s[12] = f(me.sum())
+        out13[:] = torch.tensor(s, dtype=torch.float64)
+        return out13
+
 
 ops = FakeOps()

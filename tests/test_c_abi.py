@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/pf_hip.h but not exported"
     # and the ctypes table binds exactly the declared compute entry points
-    assert set(L.SIGNATURES) == set(names) - {"pf_last_error", "pf_version"}
+    assert set(L.SIGNATURES) == set(names) - set(L.NON_STATUS)
 
 
 def test_conv_argument_validation_without_gpu():

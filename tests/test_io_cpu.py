@@ -1,0 +1,57 @@
+"""Host logic of the input / output side (patchfusion_amd/preprocess.py, postprocess.py) on the CPU: the same
+modules the GPU uses, driven through tests/fake_ops.py (torch / oracle stand-ins for the HIP kernels), checked
+against the fixtures produced from the reference's own code (tests/golden/io_side.npz)."""
+import os
+
+import numpy as np
+import torch
+
+from patchfusion_amd import postprocess as post
+from patchfusion_amd.preprocess import ImagePreprocessor
+from tests.fake_ops import ops as fake
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "io_side.npz"))
+
+
+def test_preprocessor_general_and_u4k():
+    pre = ImagePreprocessor((96, 128), (28, 37), device="cpu", ops=fake)
+    r = pre(G["img_u8"])
+    ref_hr = torch.from_numpy(G["read_image_96x128"].transpose(2, 0, 1)).float()
+    assert r["image_hr"].shape == (3, 96, 128) and torch.equal(r["image_hr"], ref_hr)
+    ref_lr = torch.nn.functional.interpolate(ref_hr[None], (28, 37), mode="bilinear", align_corners=True)[0]
+    assert torch.equal(r["image_lr"], ref_lr)
+    r = ImagePreprocessor((2160, 3840), (28, 37), dataset_name="u4k", device="cpu", ops=fake)(G["img_u8"])
+    ref = (G["img_u8"] / 255.0).astype(np.float32)[:, :, ::-1].copy()          # general_dataset.py:24-25
+    assert torch.equal(r["image_hr"], torch.from_numpy(ref.transpose(2, 0, 1).copy()))
+    try:
+        pre(np.zeros((4, 4), np.uint8))
+        raise AssertionError("expected ValueError")
+    except ValueError:
+        pass
+
+
+def test_colorize_and_uint16_host_logic():
+    d = torch.from_numpy(G["depth"])[None, None]
+    vmin, vmax = (float(np.float32(v)) for v in G["np_percentiles"])
+    for cmap in ("magma_r", "gray_r"):
+        img = post.colorize(d, vmin=vmin, vmax=vmax, cmap=cmap, ops=fake)
+        assert img.dtype == torch.uint8 and np.array_equal(img.numpy(), G[f"colorize_{cmap}"])
+        img = post.colorize(d, cmap=cmap, ops=fake)
+        assert (np.abs(img.numpy().astype(int) - G[f"colorize_{cmap}"].astype(int)).max(-1) > 0).mean() < 2e-3
+    u = post.depth_to_uint16(torch.from_numpy(np.abs(G["depth"])), ops=fake)
+    assert u.dtype == torch.uint16 and np.array_equal(u.numpy(), G["uint16"])
+
+
+def test_compute_metrics_host_logic():
+    gt, pred, edges = (torch.from_numpy(G[k]) for k in ("gt", "pred", "edges"))
+    r = post.compute_metrics(gt[None, None], pred[None, None], min_depth_eval=1e-3, max_depth_eval=80, garg_crop=False, eigen_crop=False,
+                             disp_gt_edges=edges[None], ops=fake)
+    keys = [str(k) for k in G["metrics_same_keys"]]
+    assert sorted(r) == keys
+    np.testing.assert_allclose([r[k] for k in keys], G["metrics_same"], rtol=2e-5)
+    r = post.compute_metrics(gt[None, None], torch.from_numpy(G["pred_lr"])[None, None], min_depth_eval=1e-3, max_depth_eval=80,
+                             garg_crop=True, eigen_crop=False, dataset="u4k", ops=fake)
+    keys = [str(k) for k in G["metrics_resize_garg_keys"]]
+    np.testing.assert_allclose([r[k] for k in keys], G["metrics_resize_garg"], rtol=2e-5)
+    assert post.crop_rectangle(480, 640, False, True, "nyu") == (45, 471, 41, 601)
+    assert post.crop_rectangle(100, 200, False, False, "nyu") == (0, 100, 0, 200)

@@ -131,10 +131,27 @@ __global__ __launch_bounds__(256) void pct_hist_kernel(const float* __restrict__
   __syncthreads();
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float v = x[i];
-    if (use_invalid && v == invalid) continue;
+    if (LEVEL != 0 && use_invalid && v == invalid) continue;
     const unsigned int k = f2key(v);
     if (LEVEL == 0) {
-      atomicAdd(&h[0][k >> 21], 1u);
+      // depth maps put most pixels into a handful of (sign, exponent) bins: 64 lanes hammering one LDS counter
+      // serialize.  Peel the (up to 8) most common bins of the wave with ballots - one atomic per bin - and let
+      // the stragglers add individually.
+      const unsigned int bin = k >> 21;
+      bool pending = !(use_invalid && v == invalid);
+#pragma unroll 1
+      for (int it = 0; it < 8; ++it) {
+        const unsigned long long live = __ballot(pending);
+        if (!live) break;
+        const int leader = __ffsll((long long)live) - 1;
+        const unsigned int b0 = __shfl(bin, leader, 64);
+        const unsigned long long same = __ballot(pending && bin == b0);
+        if (pending && bin == b0) {
+          pending = false;
+          if ((threadIdx.x & 63) == leader) atomicAdd(&h[0][b0], (unsigned int)__popcll(same));
+        }
+      }
+      if (pending) atomicAdd(&h[0][bin], 1u);
     } else if (LEVEL == 1) {
 #pragma unroll
       for (int r = 0; r < PCT_R; ++r)
@@ -157,35 +174,52 @@ __global__ __launch_bounds__(256) void pct_hist_kernel(const float* __restrict__
 // virtual index (n-1)*q/100 and gamma in double, (b - a) in float32, a + diff*gamma in double, and
 // b - diff*(1-gamma) instead when gamma >= 0.5.
 template <int LEVEL>
-__global__ void pct_select_kernel(PctWs* ws, double q0, double q1, float* out) {
-  __shared__ unsigned long long s_n;
-  if (LEVEL == 0) {
-    if (threadIdx.x == 0) {
-      unsigned long long n = 0;
-      for (int b = 0; b < PCT_BINS; ++b) n += ws->hist[0][b];
-      s_n = n;
-      ws->st.n = n;
-      const double q[2] = {q0, q1};
-      for (int p = 0; p < 2; ++p) {
-        const double vi = n ? (double)(n - 1) * (q[p] / 100.0) : 0.0;
-        const double lo = floor(vi);
-        unsigned long long l = (unsigned long long)lo, hgh = l + 1;
-        if (n && hgh > n - 1) hgh = n - 1;
-        ws->st.rank[2 * p] = l;
-        ws->st.rank[2 * p + 1] = n ? hgh : 0;
-        ws->st.gamma[p] = vi - lo;
-      }
-    }
-    __syncthreads();
+__global__ __launch_bounds__(256) void pct_select_kernel(PctWs* ws, double q0, double q1, float* out) {
+  constexpr int bins = LEVEL == 2 ? 1024 : 2048, NH = LEVEL == 0 ? 1 : PCT_R, PER = bins / 256;
+  __shared__ unsigned int h[NH][bins];
+  __shared__ unsigned int part[NH][256];         // sums of PER consecutive bins
+  const int tid = threadIdx.x;
+  for (int i = tid; i < NH * PCT_BINS; i += 256) {
+    const int r = i / PCT_BINS, b = i - r * PCT_BINS;
+    if (b < bins) h[r][b] = ws->hist[r][b];
   }
-  const int r = threadIdx.x;
-  if (r < PCT_R) {
-    constexpr int bins = LEVEL == 2 ? 1024 : 2048;
-    const unsigned int* h = ws->hist[LEVEL == 0 ? 0 : r];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < NH; ++r) {
+    unsigned int c = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) c += h[r][tid * PER + j];
+    part[r][tid] = c;
+  }
+  __syncthreads();
+  if (LEVEL == 0 && tid == 0) {
+    unsigned long long n = 0;
+    for (int i = 0; i < 256; ++i) n += part[0][i];
+    ws->st.n = n;
+    const double q[2] = {q0, q1};
+    for (int p = 0; p < 2; ++p) {
+      const double vi = n ? (double)(n - 1) * (q[p] / 100.0) : 0.0;
+      const double lo = floor(vi);
+      unsigned long long l = (unsigned long long)lo, hgh = l + 1;
+      if (n && hgh > n - 1) hgh = n - 1;
+      ws->st.rank[2 * p] = l;
+      ws->st.rank[2 * p + 1] = n ? hgh : 0;
+      ws->st.gamma[p] = vi - lo;
+    }
+  }
+  __syncthreads();
+  if (tid < PCT_R) {
+    const int r = tid, hr = LEVEL == 0 ? 0 : r;
     unsigned long long rank = ws->st.rank[r], cum = 0;
-    int b = 0;
-    for (; b < bins - 1; ++b) {
-      const unsigned long long c = h[b];
+    int g = 0;
+    for (; g < 255; ++g) {                        // group of PER bins that holds the rank
+      const unsigned long long c = part[hr][g];
+      if (rank < cum + c) break;
+      cum += c;
+    }
+    int b = g * PER;
+    for (; b < g * PER + PER - 1; ++b) {
+      const unsigned long long c = h[hr][b];
       if (rank < cum + c) break;
       cum += c;
     }
@@ -194,9 +228,9 @@ __global__ void pct_select_kernel(PctWs* ws, double q0, double q1, float* out) {
   }
   __syncthreads();
   if (LEVEL < 2) {
-    for (int i = threadIdx.x; i < PCT_R * PCT_BINS; i += blockDim.x) (&ws->hist[0][0])[i] = 0u;
-  } else if (threadIdx.x < 2) {
-    const int p = threadIdx.x;
+    for (int i = tid; i < PCT_R * PCT_BINS; i += 256) (&ws->hist[0][0])[i] = 0u;
+  } else if (tid < 2) {
+    const int p = tid;
     if (ws->st.n == 0) {
       out[p] = __uint_as_float(0x7fc00000u);
     } else {

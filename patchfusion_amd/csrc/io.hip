@@ -43,6 +43,10 @@ __device__ __forceinline__ void cubic_coeffs(double t, double (&c)[4]) {
   c[3] = cc2(x2 + 1.0);
 }
 
+struct __attribute__((packed, aligned(1))) Bytes12 {
+  uint32_t w[3];
+};
+
 __global__ __launch_bounds__(256) void u8_bicubic_kernel(const uint8_t* __restrict__ src, int H, int W, int reverse,
                                                          float* __restrict__ dst, int OH, int OW, double sh, double sw) {
   __shared__ double unit[256];                  // k / 255.0, the reference's first operation, exactly as numpy rounds it
@@ -66,15 +70,27 @@ __global__ __launch_bounds__(256) void u8_bicubic_kernel(const uint8_t* __restri
       int xs[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) xs[k] = min(max(ix - 1 + k, 0), W - 1) * 3;
+      const bool inner = ix >= 1 && ix + 2 <= W - 1;   // the four taps are 12 contiguous bytes: one (unaligned) load
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const uint8_t* row = src + (long)min(max(iy - 1 + j, 0), H - 1) * W * 3;
+        uint8_t tap[12];
+        if (inner) {
+          const Bytes12 q = *reinterpret_cast<const Bytes12*>(row + xs[0]);
+#pragma unroll
+          for (int e = 0; e < 12; ++e) tap[e] = (uint8_t)(q.w[e >> 2] >> (8 * (e & 3)));
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) tap[3 * k + c] = row[xs[k] + c];
+        }
         double t[3];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            const double v = unit[row[xs[k] + c]] * cx[k];
+            const double v = unit[tap[3 * k + c]] * cx[k];
             t[c] = k == 0 ? v : t[c] + v;
           }
         }

@@ -44,6 +44,16 @@ def test_tiny_fp32_matches_reference_golden(golden_dir, mode):
     assert err <= 2e-4, f"{mode}: {err}"
 
 
+def test_vitb_tiny_fp32_vs_oracle():
+    """Depth-Anything ViT-B (D=768, 12 heads, C=128): the middle encoder of the reference's three configs
+    (configs/patchfusion_depthanything/depthanything_vitb_patchfusion_u4k.py), whole path against the oracle."""
+    cfg, sd, m, img = build("vitb", (112, 154), (448, 616), (2, 2), "fp32")
+    lr = m.resizer(img)
+    d, _ = m(mode="infer", image_lr=lr.cuda(), image_hr=img.cuda(), cai_mode="m1", process_num=4)
+    ref = pf_oracle.Oracle(cfg, sd).infer(lr, img, "m1", 4)
+    assert float((d.cpu() - ref).abs().max()) < 2e-4
+
+
 def test_tiny_fp32_stage_parity_vs_oracle():
     cfg, sd, m, img = build(*TINY, "fp32")
     lr = m.resizer(img)

@@ -30,12 +30,13 @@ def test_synthetic_weights_are_deterministic_by_name():
 
 
 @pytest.mark.reference
-def test_spec_matches_reference_state_dict():
+@pytest.mark.parametrize("enc", ["vits", "vitb"])
+def test_spec_matches_reference_state_dict(enc):
     from oracle import ref_shim
     if not ref_shim.reference_available():
         pytest.skip("reference tree not present")
     PF = ref_shim.import_reference()
-    cfg = make_config("vits", (112, 154), (448, 616), (2, 2))
+    cfg = make_config(enc, (112, 154), (448, 616), (2, 2))
     with ref_shim.in_reference_cwd():
         m = PF(cfg)
     sd = m.state_dict()

@@ -86,6 +86,29 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
 }
 
+// Block id -> (tile_m, tile_n) in groups of PF_IGEMM_GROUP_M pixel tiles: consecutive ids (which xcd_remap keeps
+// on one XCD) walk GROUP_M pixel tiles x all channel tiles column by column, so the ~64 blocks an XCD runs
+// at once form a roughly square patch of the output (8 pixel tiles x 8 channel tiles) whose A and W panels fit that
+// XCD's 4 MiB L2 together, instead of 2 pixel tiles x every channel tile (the whole weight matrix streaming through L2
+// once per pair of pixel tiles).
+#ifndef PF_IGEMM_GROUP_M
+#define PF_IGEMM_GROUP_M 8
+#endif
+__device__ __forceinline__ void tile_of(int bid, int mt, int nt, int& tile_m, int& tile_n) {
+  if (PF_IGEMM_GROUP_M <= 1) {
+    tile_m = bid / nt;
+    tile_n = bid - tile_m * nt;
+    return;
+  }
+  const int per_group = PF_IGEMM_GROUP_M * nt;
+  const int group = bid / per_group;
+  const int first_m = group * PF_IGEMM_GROUP_M;
+  const int gsz = min(mt - first_m, PF_IGEMM_GROUP_M);
+  const int in_g = bid - group * per_group;
+  tile_n = in_g / gsz;
+  tile_m = first_m + (in_g - tile_n * gsz);
+}
+
 template <typename T, int BM, int BN, int WM, int WN, bool RELU_IN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p) {
   constexpr int VEC = Elem<T>::VEC;
@@ -105,7 +128,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
   const int M = p.B * OHW;
   const int nt = (p.Cout + BN - 1) / BN;
   const int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-  const int tile_m = bid / nt, tile_n = bid - tile_m * nt;
+  int tile_m, tile_n;
+  tile_of(bid, (M + BM - 1) / BM, nt, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // ---- loader state.  One LDS-DMA instruction (global_load_lds_dwordx4) moves 1 KiB = 8 tile rows x
@@ -145,7 +169,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
     b_ptr[i] = (row < p.w_rows) ? reinterpret_cast<const char*>(wg + (long)row * p.Kpad + j * VEC) : nullptr;
   }
   const int cin_v = p.Cin / VEC;
+#ifdef PF_ABL_ONECHUNK     // measurement build: one K chunk only = launch + prologue + epilogue cost of the kernel
+  const int nk = 1;
+#else
   const int nk = (ntaps * cin_v + 7) / 8;
+#endif
   // this thread's K position: vector index kv = kc*8 + j  ->  (tap = (ky,kx), cv)
   int tap = j / cin_v, cv = j - tap * cin_v;
   int ky = tap / p.KW, kx = tap - ky * p.KW;
@@ -214,11 +242,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
 
   // fragment read addressing: lane (r, g); tile rows are multiples of 16 so the swizzle term is per-lane
   const int fr = lane & 15, fg = lane >> 4;
+  // per-channel epilogue constants are fetched NOW: their global-load latency (1-2 us, once per block, a tenth of
+  // a K=1024 GEMM block's life) hides behind the K loop instead of sitting between the last MFMA and the stores
+  float4 bias_r[FN], scale_r[FN];
+#pragma unroll
+  for (int fn = 0; fn < FN; ++fn) {
+    const int n = n0 + wn * WTN + fn * 16 + fg * 4;
+    bias_r[fn] = make_float4(0.f, 0.f, 0.f, 0.f);
+    scale_r[fn] = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (p.shuffle <= 1 && n < p.Cout) {
+      if (p.bias) bias_r[fn] = *reinterpret_cast<const float4*>(p.bias + n);
+      if (p.scale) scale_r[fn] = *reinterpret_cast<const float4*>(p.scale + n);
+    }
+  }
   const int swz = (fr >> 1) & 7;
   const int a_row_off = (wm * WTM + fr) * 128;  // activations (pixels)
   const int b_row_off = (wn * WTN + fr) * 128;  // weights (channels)
 
+#ifndef PF_ABL_NOPRO
   issue(0, 0);
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int kc = 0; kc < nk; ++kc) {
@@ -272,9 +315,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
         opix = ((long)b * (p.OH * s) + (oy * s + dy)) * (p.OW * s) + (ox * s + dx);
       }
       float v[4] = {acc[fn][fm][0], acc[fn][fm][1], acc[fn][fm][2], acc[fn][fm][3]};
-      if (p.bias) {
+      if (s > 1) {
+        if (p.bias) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += p.bias[co + r];
+          for (int r = 0; r < 4; ++r) v[r] += p.bias[co + r];
+        }
+      } else {
+        v[0] += bias_r[fn].x; v[1] += bias_r[fn].y; v[2] += bias_r[fn].z; v[3] += bias_r[fn].w;
       }
       if (p.act == PF_ACT_RELU) {
 #pragma unroll
@@ -286,9 +333,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = softplus20(v[r]);
       }
-      if (p.scale) {
+      if (s > 1) {
+        if (p.scale) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= p.scale[co + r];
+          for (int r = 0; r < 4; ++r) v[r] *= p.scale[co + r];
+        }
+      } else {
+        v[0] *= scale_r[fn].x; v[1] *= scale_r[fn].y; v[2] *= scale_r[fn].z; v[3] *= scale_r[fn].w;
       }
       if (p.res) {
         float t[4];
@@ -302,8 +353,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += t[r];
       }
+#ifdef PF_ABL_NOSTORE
+      if (v[0] == 12345.678f) store4(reinterpret_cast<T*>(p.y) + opix * p.y_ld + co, v[0], v[1], v[2], v[3]);
+#else
       if (p.out_f32) store4(reinterpret_cast<float*>(p.y) + opix * p.y_ld + co, v[0], v[1], v[2], v[3]);
       else store4(reinterpret_cast<T*>(p.y) + opix * p.y_ld + co, v[0], v[1], v[2], v[3]);
+#endif
     }
   }
 }
@@ -339,7 +394,8 @@ __global__ __launch_bounds__(512) void conv_igemm_big_kernel(const pf_conv_param
   const int M = p.B * OHW;
   const int nt = (p.Cout + BN - 1) / BN;
   const int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-  const int tile_m = bid / nt, tile_n = bid - tile_m * nt;
+  int tile_m, tile_n;
+  tile_of(bid, (M + BM - 1) / BM, nt, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int r0 = tid >> 3;                       // 0..63

@@ -134,6 +134,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        barrier()                      # the other ranks wait for rank 0's roofline launch, then all leave together
         torch.distributed.destroy_process_group()
 
 

@@ -364,6 +364,200 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
 }
 
 // -------------------------------------------------------------------------------------------------
+// EXPERIMENTAL (opt-in: PF_GEMM_PERSIST=1; not dispatched by default, see DESIGN.md 4a "next"): persistent variant of
+// the 1x1 / linear fast path of conv_igemm_kernel for bf16.  The measured life of a K=1024 ViT linear block is only
+// ~55 % K loop; the rest is launch + per-block set-up, the first chunk's DMA latency and the epilogue.  Here
+// 2 blocks per CU stay resident and walk the output tiles (ids b, b+G, b+2G, ... in the grouped order of tile_of);
+// the K chunks of consecutive tiles form ONE stream through the two LDS stages, so the first chunk of tile t+1 is
+// fetched while the last chunk of tile t is multiplied, and its second chunk while tile t's epilogue runs.
+// Chunk k always lives in stage k&1 and is issued after the barrier that ends chunk k-2, exactly as in the
+// one-tile kernel; `issued` counts chunks handed to the DMA engine, the cursor (it_*) is the tile/offset they
+// come from.  Requirements (checked by the dispatcher): KH=KW=1, stride 1, pad 0, no shuffle, Cin % 64 == 0, Cin >= 128.
+// -------------------------------------------------------------------------------------------------
+template <int BN, bool RELU_IN>
+__global__ __launch_bounds__(256) void gemm_persist_kernel(const pf_conv_params p) {
+  using T = bf16_t;
+  constexpr int BM = 128, WM = 2, WN = 2;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int FM = WTM / 16, FN = WTN / 16;
+  constexpr int A_ITERS = BM / 32, B_ITERS = (BN + 31) / 32;
+  constexpr int A_BYTES = BM * 128, B_BYTES = B_ITERS * 32 * 128, STAGE = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int M = p.B * p.OH * p.OW;
+  const int mt = (M + BM - 1) / BM, nt = (p.Cout + BN - 1) / BN;
+  const int T_all = mt * nt, G = (int)gridDim.x;
+  const int lid = xcd_remap((int)blockIdx.x, G);          // blocks of one XCD take neighbouring tiles
+  const int my_tiles = lid < T_all ? (T_all - lid + G - 1) / G : 0;
+  const int nk = p.Cin / 64;
+  const int total = my_tiles * nk;                        // chunks of this block's whole stream
+  if (total == 0) return;
+
+  const int r0 = tid >> 3;
+  const int j = (tid & 7) ^ ((r0 >> 1) & 7);              // source-side swizzle, as in conv_igemm_kernel
+  const char* __restrict__ xg = reinterpret_cast<const char*>(p.x);
+  const char* __restrict__ wg = reinterpret_cast<const char*>(p.w);
+  const char* zero = reinterpret_cast<const char*>(pf_zero_page);
+  const unsigned smem_base = lds_addr(smem);
+
+  // ---- issue cursor: the tile / K offset the NEXT chunk handed to the DMA engine comes from ----
+  const char* a_cur[A_ITERS];
+  const char* b_cur[B_ITERS];
+  int a_inc[A_ITERS], b_inc[B_ITERS];
+  int it_tile = lid, it_kc = 0, issued = 0;
+  auto cursor_to_tile = [&](int t) {
+    int tm, tn;
+    tile_of(t, mt, nt, tm, tn);
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      const int m = tm * BM + r0 + 32 * i;
+      const bool ok = m < M;
+      a_cur[i] = ok ? xg + ((long)m * p.x_ld + j * 8) * 2 : zero;
+      a_inc[i] = ok ? 128 : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i) {
+      const int row = tn * BN + r0 + 32 * i;
+      const bool ok = (r0 + 32 * i) < BN && row < p.w_rows;
+      b_cur[i] = ok ? wg + ((long)row * p.Kpad + j * 8) * 2 : zero;
+      b_inc[i] = ok ? 128 : 0;
+    }
+  };
+  auto issue_next = [&]() {
+    const unsigned As = smem_base + (issued & 1) * STAGE + wave * (8 * 128);
+    const unsigned Bs = As + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      glds16(a_cur[i], As + i * (32 * 128));
+      a_cur[i] += a_inc[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i) {
+      glds16(b_cur[i], Bs + i * (32 * 128));
+      b_cur[i] += b_inc[i];
+    }
+    ++issued;
+    if (++it_kc == nk) {
+      it_kc = 0;
+      it_tile += G;
+      if (it_tile < T_all) cursor_to_tile(it_tile);
+    }
+  };
+
+  const int fr = lane & 15, fg = lane >> 4;
+  const int swz = (fr >> 1) & 7;
+  const int a_row_off = (wm * WTM + fr) * 128;
+  const int b_row_off = (wn * WTN + fr) * 128;
+
+  cursor_to_tile(it_tile);
+  issue_next();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int c = 0;                                              // chunk being multiplied
+  for (int t = lid; t < T_all; t += G) {
+    int tile_m, tile_n;
+    tile_of(t, mt, nt, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm) acc[fn][fm] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 bias_r[FN], scale_r[FN];
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) {
+      const int n = n0 + wn * WTN + fn * 16 + fg * 4;
+      bias_r[fn] = make_float4(0.f, 0.f, 0.f, 0.f);
+      scale_r[fn] = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (n < p.Cout) {
+        if (p.bias) bias_r[fn] = *reinterpret_cast<const float4*>(p.bias + n);
+        if (p.scale) scale_r[fn] = *reinterpret_cast<const float4*>(p.scale + n);
+      }
+    }
+    for (int kc = 0; kc < nk; ++kc, ++c) {
+      if (issued == c + 1 && issued < total) issue_next();           // keep one chunk ahead (skipped when two ahead)
+      const char* As = smem + (c & 1) * STAGE;
+      const char* Bs = As + A_BYTES;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int slot = (((s << 2) | fg) ^ swz) << 4;
+        uint4 wf[FN], xf[FM];
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) wf[fn] = *reinterpret_cast<const uint4*>(Bs + b_row_off + fn * 16 * 128 + slot);
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+          xf[fm] = *reinterpret_cast<const uint4*>(As + a_row_off + fm * 16 * 128 + slot);
+          if constexpr (RELU_IN) xf[fm] = relu_vec<T>(xf[fm]);
+        }
+        mma_half_bf16<FM, FN>(wf, xf, acc);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    // tile finished: its last stage is free -> put the NEXT tile's second chunk in flight behind the epilogue
+    if (issued == c + 1 && issued < total) issue_next();
+    // ---- epilogue (same order as conv_igemm_kernel: bias -> act -> scale -> residual(s) -> store) ----
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) {
+      const int m = m0 + wm * WTM + fm * 16 + fr;
+      if (m >= M) continue;
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn) {
+        const int n = n0 + wn * WTN + fn * 16 + fg * 4;
+        if (n >= p.Cout) continue;
+        float v[4] = {acc[fn][fm][0] + bias_r[fn].x, acc[fn][fm][1] + bias_r[fn].y, acc[fn][fm][2] + bias_r[fn].z,
+                      acc[fn][fm][3] + bias_r[fn].w};
+        if (p.act == PF_ACT_RELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        } else if (p.act == PF_ACT_GELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+        } else if (p.act == PF_ACT_SOFTPLUS) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = softplus20(v[r]);
+        }
+        v[0] *= scale_r[fn].x; v[1] *= scale_r[fn].y; v[2] *= scale_r[fn].z; v[3] *= scale_r[fn].w;
+        if (p.res) {
+          float r4[4];
+          load4(reinterpret_cast<const T*>(p.res) + (long)m * p.res_ld + n, r4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += r4[r];
+        }
+        if (p.res2) {
+          float r4[4];
+          load4(reinterpret_cast<const T*>(p.res2) + (long)m * p.res2_ld + n, r4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += r4[r];
+        }
+        if (p.out_f32) store4(reinterpret_cast<float*>(p.y) + (long)m * p.y_ld + n, v[0], v[1], v[2], v[3]);
+        else store4(reinterpret_cast<T*>(p.y) + (long)m * p.y_ld + n, v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+template <int BN, bool RELU_IN>
+int launch_persist(const pf_conv_params& p, hipStream_t st) {
+  constexpr int smem = 2 * (128 + ((BN + 31) / 32) * 32) * 128;
+  static bool attr_set = false;
+  auto kern = gemm_persist_kernel<BN, RELU_IN>;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  const long M = (long)p.B * p.OH * p.OW;
+  const long tiles = ((M + 127) / 128) * ((p.Cout + BN - 1) / BN);
+  const long slots = 256L * (BN <= 64 ? 3 : 2);          // resident blocks: LDS 48 / 56 / 64 KiB per block
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles < slots ? tiles : slots)), dim3(256), smem, st, p);
+  return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_LAUNCH;
+}
+
+// -------------------------------------------------------------------------------------------------
 // "big" bf16 variant for the layers that carry the FLOPs (Cout >= 96, many pixels):
 // 512 threads = 8 waves (4 along pixels x 2 along channels), block tile 256 pixels x 128 channels, per-wave
 // 64x64 from 2x2 v_mfma_f32_32x32x16_bf16 fragments, K chunks of 64 through a THREE-deep LDS-DMA ring
@@ -1091,6 +1285,32 @@ int dispatch(const pf_conv_params& p, hipStream_t st) {
       if (fn_force == 2) return p.relu_in ? launch_halo<2, 4, 2, true>(p, st) : launch_halo<2, 4, 2, false>(p, st);
       if (pad192 <= pad128) return p.relu_in ? launch_halo<2, 4, 3, true>(p, st) : launch_halo<2, 4, 3, false>(p, st);
       return p.relu_in ? launch_halo<2, 4, 2, true>(p, st) : launch_halo<2, 4, 2, false>(p, st);
+    }
+  }
+  if constexpr (sizeof(T) == 2) {
+    // experimental persistent GEMM (see gemm_persist_kernel): opt-in only until it is validated and tuned on hardware
+    static int persist = -1;
+    if (persist < 0) { const char* e = getenv("PF_GEMM_PERSIST"); persist = e ? atoi(e) : 0; }
+    if (persist > 0 && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.shuffle <= 1 && p.Cin % 64 == 0 && p.Cin >= 128 &&
+        p.Cout >= 64 && M >= 1024) {
+      int bn = persist;
+      if (bn != 128 && bn != 96 && bn != 64) {
+        // static schedule: block b takes tiles b, b+G, ...: the makespan is ceil(tiles / resident blocks) tiles per
+        // block, every CU running `occ` of them side by side (8296 x 1024 outputs: 520 tiles of 128x128 on 512
+        // resident blocks would be two rounds for 1.6 % more work)
+        double best = 1e300;
+        const int cand[3] = {128, 96, 64};
+        for (int i = 0; i < 3; ++i) {
+          const int occ = cand[i] <= 64 ? 3 : 2;
+          const long tiles = ((M + 127) / 128) * ((p.Cout + cand[i] - 1) / cand[i]);
+          const long rounds = (tiles + 256L * occ - 1) / (256L * occ);
+          const double cost = (double)rounds * occ * 128.0 * cand[i];
+          if (cost < best) { best = cost; bn = cand[i]; }
+        }
+      }
+      if (bn == 128) return p.relu_in ? launch_persist<128, true>(p, st) : launch_persist<128, false>(p, st);
+      if (bn == 96) return p.relu_in ? launch_persist<96, true>(p, st) : launch_persist<96, false>(p, st);
+      return p.relu_in ? launch_persist<64, true>(p, st) : launch_persist<64, false>(p, st);
     }
   }
   const TileCfg cfgs[6] = {{256, 128, 1, 1.0f, 0}, {128, 128, 2, 1.0f, 1}, {128, 96, 2, 0.97f, 2},

@@ -1,0 +1,50 @@
+"""Opt-in checks of kernels that are NOT dispatched by default (skipped unless PF_TEST_EXPERIMENTAL=1).
+
+  PF_TEST_EXPERIMENTAL=1 PF_GEMM_PERSIST=1 python -m pytest tests/test_experimental_gpu.py -m gpu -q
+
+PF_GEMM_PERSIST (1 = automatic channel tile, or 128 / 96 / 64) routes every bf16 1x1 / linear layer with
+Cin % 64 == 0, Cin >= 128, Cout >= 64 and >= 1024 rows to the persistent GEMM (`gemm_persist_kernel`,
+patchfusion_amd/csrc/igemm.hip); the environment variable is read once per process, hence the separate invocation.
+"""
+import os
+
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("PF_TEST_EXPERIMENTAL") != "1", reason="experimental kernels are opt-in")]
+
+
+@pytest.mark.parametrize("case", [
+    # B, H, W, cin, cout, kwargs: ViT-like linears (ragged M = 2*1037, 8*1037), epilogue variants, channel tails
+    (1, 1, 2 * 1037, 384, 1152, {}),
+    (1, 1, 8 * 1037, 1024, 1024, dict(scale=True, res=True, inplace=True)),
+    (1, 1, 8 * 1037, 1024, 4096, dict(act="gelu")),
+    (1, 1, 4 * 1037, 4096, 1024, dict(scale=True, res=True)),
+    (2, 56, 74, 256, 160, dict(act="relu", y_extra=32)),          # Cout tail inside a channel tile, output slice
+    (2, 40, 52, 128, 64, dict(relu_in=True, res=True, res2=True)),
+    (1, 33, 47, 192, 80, dict(act="gelu", out_f32=True)),
+])
+def test_persistent_gemm_matches_reference(case):
+    from tests import op_checks
+    assert int(os.environ.get("PF_GEMM_PERSIST", "0")) > 0, "set PF_GEMM_PERSIST to route the GEMMs to the persistent kernel"
+    B, H, W, cin, cout, kw = case
+    err, tol, name = op_checks._conv_case(torch.bfloat16, B, H, W, cin, cout, 1, seed=41, **kw)
+    assert err <= tol, (name, err)
+
+
+def test_persistent_gemm_is_deterministic():
+    import hashlib
+    from patchfusion_amd import packing as pk
+    from patchfusion_amd.hip_ops import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 1, 8296, 1024, generator=g).to(torch.bfloat16).cuda()
+    pw = pk.pack_conv(torch.randn(3072, 1024, generator=g) / 32, torch.randn(3072, generator=g), dtype=torch.bfloat16).to("cuda")
+    hs = set()
+    for _ in range(8):
+        y = torch.full((1, 1, 8296, 3072), float("nan"), dtype=torch.bfloat16, device="cuda")
+        ops.conv(x, pw, y)
+        torch.cuda.synchronize()
+        assert torch.isfinite(y.float()).all()
+        hs.add(hashlib.sha256(y.view(torch.int16).cpu().numpy().tobytes()).hexdigest())
+    assert len(hs) == 1

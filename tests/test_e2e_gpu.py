@@ -120,6 +120,22 @@ def test_vitl_patch_batch_vs_oracle_on_gpu():
         torch.cuda.empty_cache()
 
 
+def test_headline_size_schedule_properties():
+    """BASELINE.json configs[2] itself (Depth-Anything ViT-L, 2160x3840, 4x4 tiles, process_num 8, bf16): the oracle
+    needs minutes per tile on a CPU, so the full-size pass is checked through size-independent properties
+    (tests/schedule_props.py): determinism, stream-schedule invariance (bit-exact), batch-size invariance within the
+    bf16 tolerance of test_vitl_patch_batch_vs_oracle_on_gpu, finite / in-range / reensemble-shaped output."""
+    from tests import schedule_props
+    cfg, sd, m, img = build("vitl", (392, 518), (2160, 3840), (4, 4), "bf16")
+    img = img.cuda()
+    lr = m.resizer(img)
+    d = m(mode="infer", image_lr=lr, image_hr=img, cai_mode="m1", process_num=8)[0]
+    s = float(d.float().std())
+    schedule_props.check(m, lr, img, cfg, process_num=8, max_tol=max(0.5 * s, 1e-3), mean_tol=max(0.08 * s, 1e-4))
+    del m
+    torch.cuda.empty_cache()
+
+
 def test_baseline_pretrain_fine_and_coarse_vs_oracle():
     """BaselinePretrain on the HIP engine: coarse branch and tiled fine branch (m2) vs oracle."""
     from collections import OrderedDict

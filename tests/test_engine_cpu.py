@@ -73,6 +73,13 @@ def test_end_to_end_matches_golden(tiny, golden_dir, mode):
     assert aux["depth_pred"] is d and aux["rgb"] is lr
 
 
+def test_schedule_properties_tiny(tiny):
+    """The same property checker the GPU runs at the headline size (tests/schedule_props.py)."""
+    from tests import schedule_props
+    cfg, sd, m, img = tiny
+    schedule_props.check(m, m.resizer(img), img, cfg, process_num=4, max_tol=1e-5, mean_tol=1e-6)
+
+
 def test_errors_match_reference_contract(tiny):
     cfg, sd, m, img = tiny
     with pytest.raises(AssertionError):

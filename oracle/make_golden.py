@@ -11,6 +11,10 @@ tools/test.py:122-123 fix_random_seed):
               full output maps + coarse depth + sampled coarse features
   full_vits : DA-vits, process 392x518, raw 784x1036, split 2x2, process_num=4, mode m1, 8192
               sampled output values + stats (kept small)
+  cfg4k_vits: BASELINE.json configs[0] and configs[1] themselves - DA-vits, 2160x3840 image:
+              2x2 tiles, cai_mode r4, process_num=4 (13 patches; SURVEY 8d "Config 1") and
+              4x4 tiles, cai_mode m1, process_num=4 (16 patches; "Config 2"); 16384 sampled values each
+              (`python -m oracle.make_golden cfg4k` regenerates only this file; ~5 CPU-minutes)
 """
 import os
 import random
@@ -45,9 +49,32 @@ def build(enc, ps, raw, split):
     return m, cfg, img
 
 
+def cfg4k():
+    """BASELINE.json configs[0] / configs[1] at their real size, from the reference itself."""
+    out = {}
+    for name, split, mode in (("c0_2x2_r4", (2, 2), "r4"), ("c1_4x4_m1", (4, 4), "m1")):
+        m, cfg, img = build("vits", (392, 518), (2160, 3840), split)
+        lr = m.resizer(img)
+        with torch.no_grad():
+            random.seed(5621)
+            d, _ = m(mode="infer", image_lr=lr, image_hr=img, cai_mode=mode, process_num=4)
+        flat = d.flatten()
+        idx = sample_idx(flat.numel(), 16384, 11)
+        out[name + "_shape"] = np.array(d.shape[2:], np.int64)
+        out[name + "_idx"] = idx
+        out[name + "_val"] = flat[idx].numpy()
+        out[name + "_stats"] = np.array([d.mean().item(), d.std().item(), d.min().item(), d.max().item()], np.float32)
+        print(name, tuple(d.shape), out[name + "_stats"], flush=True)
+        del m
+    np.savez_compressed(os.path.join(OUT, "cfg4k_vits.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
+    if len(sys.argv) > 1 and sys.argv[1] == "cfg4k":
+        cfg4k()
+        return
     # ---------------- tiny ----------------
     m, cfg, img = build("vits", (112, 154), (448, 616), (2, 2))
     lr = m.resizer(img)
@@ -83,6 +110,7 @@ def main():
         out[name + "_stats"] = np.array([t.mean().item(), t.std().item(), t.min().item(), t.max().item()], np.float32)
     np.savez_compressed(os.path.join(OUT, "full_vits.npz"), **out)
     print("full_vits done", out["depth_m1_stats"])
+    cfg4k()
 
 
 if __name__ == "__main__":

@@ -95,6 +95,23 @@ def test_full_size_vits_fp32_matches_reference_golden(golden_dir):
     assert np.abs(c - g["coarse_depth_val"]).max() <= 2e-4
 
 
+@pytest.mark.parametrize("name,split,mode", [("c0_2x2_r4", (2, 2), "r4"), ("c1_4x4_m1", (4, 4), "m1")])
+def test_baseline_configs_0_and_1_match_reference_golden(golden_dir, name, split, mode):
+    """BASELINE.json configs[0] (DA-vits, one 2160x3840 image, 2x2 tiles + random tiles `r4`, 13 patches) and configs[1]
+    (DA-vits, 4K, 4x4 regular tiling, batch 4) at their real size: 16384 sampled outputs of the REFERENCE's own run
+    (tests/golden/cfg4k_vits.npz, oracle/make_golden.py cfg4k), fp32 mode, same 2e-4 bound as the small fixtures."""
+    g = np.load(os.path.join(golden_dir, "cfg4k_vits.npz"))
+    cfg, sd, m, img = build("vits", (392, 518), (2160, 3840), split, "fp32")
+    lr = m.resizer(img).cuda()
+    random.seed(5621)
+    d, _ = m(mode="infer", image_lr=lr, image_hr=img.cuda(), cai_mode=mode, process_num=4)
+    assert tuple(d.shape[2:]) == tuple(int(v) for v in g[name + "_shape"])
+    v = d.flatten().cpu()[torch.from_numpy(g[name + "_idx"])].numpy()
+    assert np.abs(v - g[name + "_val"]).max() <= 2e-4
+    del m
+    torch.cuda.empty_cache()
+
+
 def test_vitl_patch_batch_vs_oracle_on_gpu():
     """Depth-Anything ViT-L (the headline model) at the full 392x518 process shape, one fine+fusion batch
     of 2 tiles, engine (fp32 and bf16) vs the oracle evaluated with torch on the same GPU."""

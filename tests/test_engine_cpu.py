@@ -73,6 +73,24 @@ def test_end_to_end_matches_golden(tiny, golden_dir, mode):
     assert aux["depth_pred"] is d and aux["rgb"] is lr
 
 
+@pytest.mark.skipif(os.environ.get("PF_TEST_FAST") == "1", reason="about one CPU-minute; PF_TEST_FAST=1 skips it")
+@pytest.mark.parametrize("name,split,mode", [("c0_2x2_r4", (2, 2), "r4"), ("c1_4x4_m1", (4, 4), "m1")])
+def test_host_logic_at_baseline_configs_0_and_1(golden_dir, name, split, mode):
+    """BASELINE.json configs[0] / [1] at 2160x3840 through the product's host code (tiling, tile tables, random-tile
+    schedule, stitcher, weight packing) with the torch stand-in ops: 16384 sampled outputs of the reference's own runs."""
+    g = np.load(os.path.join(golden_dir, "cfg4k_vits.npz"))
+    cfg = make_config("vits", (392, 518), (2160, 3840), split)
+    m = PatchFusion(cfg, compute_dtype="fp32", ops=fake_ops).eval()
+    m.load_state_dict(synthetic_state_dict(patchfusion_spec(cfg), 0), strict=True)
+    img = torch.rand(1, 3, 2160, 3840, generator=torch.Generator().manual_seed(1234))
+    random.seed(5621)
+    with torch.no_grad():
+        d, _ = m(mode="infer", image_lr=m.resizer(img), image_hr=img, cai_mode=mode, process_num=4)
+    assert tuple(d.shape[2:]) == tuple(int(v) for v in g[name + "_shape"])
+    v = d.flatten()[torch.from_numpy(g[name + "_idx"])].numpy()
+    assert np.abs(v - g[name + "_val"]).max() <= 1e-5
+
+
 def test_schedule_properties_tiny(tiny):
     """The same property checker the GPU runs at the headline size (tests/schedule_props.py)."""
     from tests import schedule_props

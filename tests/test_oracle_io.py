@@ -4,7 +4,6 @@ read_image / colorize / compute_metrics in the build container."""
 import os
 
 import numpy as np
-import pytest
 import torch
 
 from oracle import io_oracle as io

@@ -374,14 +374,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
 // one-tile kernel; `issued` counts chunks handed to the DMA engine, the cursor (it_*) is the tile/offset they
 // come from.  Requirements (checked by the dispatcher): KH=KW=1, stride 1, pad 0, no shuffle, Cin % 64 == 0, Cin >= 128.
 // -------------------------------------------------------------------------------------------------
-template <int BN, bool RELU_IN>
-__global__ __launch_bounds__(256) void gemm_persist_kernel(const pf_conv_params p) {
+template <int BM, int BN, int WM, int WN, bool RELU_IN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_persist_kernel(const pf_conv_params p) {
   using T = bf16_t;
-  constexpr int BM = 128, WM = 2, WN = 2;
+  constexpr int NT = 64 * WM * WN, RP = NT / 8;             // threads; tile rows moved per loader pass (8 per wave)
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int FM = WTM / 16, FN = WTN / 16;
-  constexpr int A_ITERS = BM / 32, B_ITERS = (BN + 31) / 32;
-  constexpr int A_BYTES = BM * 128, B_BYTES = B_ITERS * 32 * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_ITERS = (BM + RP - 1) / RP, B_ITERS = (BN + RP - 1) / RP;
+  constexpr int A_BYTES = A_ITERS * RP * 128, B_BYTES = B_ITERS * RP * 128, STAGE = A_BYTES + B_BYTES;
+  static_assert(WTM % 16 == 0 && WTN % 16 == 0 && RP % 16 == 0, "fragment multiples; the loader swizzle needs RP % 16 == 0");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -413,15 +414,15 @@ __global__ __launch_bounds__(256) void gemm_persist_kernel(const pf_conv_params 
     tile_of(t, mt, nt, tm, tn);
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
-      const int m = tm * BM + r0 + 32 * i;
-      const bool ok = m < M;
+      const int m = tm * BM + r0 + RP * i;
+      const bool ok = (r0 + RP * i) < BM && m < M;
       a_cur[i] = ok ? xg + ((long)m * p.x_ld + j * 8) * 2 : zero;
       a_inc[i] = ok ? 128 : 0;
     }
 #pragma unroll
     for (int i = 0; i < B_ITERS; ++i) {
-      const int row = tn * BN + r0 + 32 * i;
-      const bool ok = (r0 + 32 * i) < BN && row < p.w_rows;
+      const int row = tn * BN + r0 + RP * i;
+      const bool ok = (r0 + RP * i) < BN && row < p.w_rows;
       b_cur[i] = ok ? wg + ((long)row * p.Kpad + j * 8) * 2 : zero;
       b_inc[i] = ok ? 128 : 0;
     }
@@ -431,12 +432,12 @@ __global__ __launch_bounds__(256) void gemm_persist_kernel(const pf_conv_params 
     const unsigned Bs = As + A_BYTES;
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
-      glds16(a_cur[i], As + i * (32 * 128));
+      glds16(a_cur[i], As + i * (RP * 128));
       a_cur[i] += a_inc[i];
     }
 #pragma unroll
     for (int i = 0; i < B_ITERS; ++i) {
-      glds16(b_cur[i], Bs + i * (32 * 128));
+      glds16(b_cur[i], Bs + i * (RP * 128));
       b_cur[i] += b_inc[i];
     }
     ++issued;
@@ -541,19 +542,28 @@ __global__ __launch_bounds__(256) void gemm_persist_kernel(const pf_conv_params 
   }
 }
 
-template <int BN, bool RELU_IN>
+// candidate shapes of the persistent GEMM: {BM, BN, WM, WN}; resident blocks per CU follow from the 160 KiB of LDS
+template <int BM, int BN, int WM, int WN>
+struct PersistCfg {
+  static constexpr int RP = 8 * WM * WN;
+  static constexpr int smem = 2 * (((BM + RP - 1) / RP) * RP + ((BN + RP - 1) / RP) * RP) * 128;
+  static constexpr int occ = (160 * 1024) / smem;
+};
+
+template <int BM, int BN, int WM, int WN, bool RELU_IN>
 int launch_persist(const pf_conv_params& p, hipStream_t st) {
-  constexpr int smem = 2 * (128 + ((BN + 31) / 32) * 32) * 128;
+  using C = PersistCfg<BM, BN, WM, WN>;
+  constexpr int smem = C::smem;
   static bool attr_set = false;
-  auto kern = gemm_persist_kernel<BN, RELU_IN>;
+  auto kern = gemm_persist_kernel<BM, BN, WM, WN, RELU_IN>;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   const long M = (long)p.B * p.OH * p.OW;
-  const long tiles = ((M + 127) / 128) * ((p.Cout + BN - 1) / BN);
-  const long slots = 256L * (BN <= 64 ? 3 : 2);          // resident blocks: LDS 48 / 56 / 64 KiB per block
-  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles < slots ? tiles : slots)), dim3(256), smem, st, p);
+  const long tiles = ((M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
+  const long slots = 256L * C::occ;                      // resident blocks
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles < slots ? tiles : slots)), dim3(64 * WM * WN), smem, st, p);
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_LAUNCH;
 }
 
@@ -1288,29 +1298,40 @@ int dispatch(const pf_conv_params& p, hipStream_t st) {
     }
   }
   if constexpr (sizeof(T) == 2) {
-    // experimental persistent GEMM (see gemm_persist_kernel): opt-in only until it is validated and tuned on hardware
-    static int persist = -1;
-    if (persist < 0) { const char* e = getenv("PF_GEMM_PERSIST"); persist = e ? atoi(e) : 0; }
+    // experimental persistent GEMM (see gemm_persist_kernel): opt-in only until it is validated and tuned on hardware.
+    // PF_GEMM_PERSIST (read per call): 1 = pick the shape by the makespan model below, or force "BMxBN" by its code
+    // 128128 / 12896 / 12864 / 144128 / 14464.
+    const char* pe = getenv("PF_GEMM_PERSIST");
+    const int persist = pe ? atoi(pe) : 0;
     if (persist > 0 && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.shuffle <= 1 && p.Cin % 64 == 0 && p.Cin >= 128 &&
         p.Cout >= 64 && M >= 1024) {
-      int bn = persist;
-      if (bn != 128 && bn != 96 && bn != 64) {
-        // static schedule: block b takes tiles b, b+G, ...: the makespan is ceil(tiles / resident blocks) tiles per
-        // block, every CU running `occ` of them side by side (8296 x 1024 outputs: 520 tiles of 128x128 on 512
-        // resident blocks would be two rounds for 1.6 % more work)
+      // static schedule: block b takes tiles b, b+G, ...; every CU runs `occ` blocks side by side, so the makespan is
+      // ceil(tiles / (256 occ)) tiles per block at occ tiles per CU-time (8296 x 1024 outputs: 520 tiles of 128x128
+      // on 512 resident blocks are two rounds; 464 tiles of 144x128 are one)
+      struct Cand { int code, bm, bn, occ; };
+      const Cand cand[5] = {{128128, 128, 128, PersistCfg<128, 128, 2, 2>::occ}, {12896, 128, 96, PersistCfg<128, 96, 2, 2>::occ},
+                            {12864, 128, 64, PersistCfg<128, 64, 2, 2>::occ}, {144128, 144, 128, PersistCfg<144, 128, 3, 2>::occ},
+                            {14464, 144, 64, PersistCfg<144, 64, 3, 2>::occ}};
+      int code = persist;
+      bool known = false;
+      for (int i = 0; i < 5; ++i) known = known || cand[i].code == code;
+      if (!known) {
         double best = 1e300;
-        const int cand[3] = {128, 96, 64};
-        for (int i = 0; i < 3; ++i) {
-          const int occ = cand[i] <= 64 ? 3 : 2;
-          const long tiles = ((M + 127) / 128) * ((p.Cout + cand[i] - 1) / cand[i]);
-          const long rounds = (tiles + 256L * occ - 1) / (256L * occ);
-          const double cost = (double)rounds * occ * 128.0 * cand[i];
-          if (cost < best) { best = cost; bn = cand[i]; }
+        for (int i = 0; i < 5; ++i) {
+          const long tiles = ((M + cand[i].bm - 1) / cand[i].bm) * ((p.Cout + cand[i].bn - 1) / cand[i].bn);
+          const long rounds = (tiles + 256L * cand[i].occ - 1) / (256L * cand[i].occ);
+          const double cost = (double)rounds * cand[i].occ * cand[i].bm * cand[i].bn;
+          if (cost < best) { best = cost; code = cand[i].code; }
         }
       }
-      if (bn == 128) return p.relu_in ? launch_persist<128, true>(p, st) : launch_persist<128, false>(p, st);
-      if (bn == 96) return p.relu_in ? launch_persist<96, true>(p, st) : launch_persist<96, false>(p, st);
-      return p.relu_in ? launch_persist<64, true>(p, st) : launch_persist<64, false>(p, st);
+#define PF_PERSIST_CASE(CODE, BM_, BN_, WM_, WN_) \
+      if (code == CODE) return p.relu_in ? launch_persist<BM_, BN_, WM_, WN_, true>(p, st) : launch_persist<BM_, BN_, WM_, WN_, false>(p, st);
+      PF_PERSIST_CASE(128128, 128, 128, 2, 2)
+      PF_PERSIST_CASE(12896, 128, 96, 2, 2)
+      PF_PERSIST_CASE(12864, 128, 64, 2, 2)
+      PF_PERSIST_CASE(144128, 144, 128, 3, 2)
+      PF_PERSIST_CASE(14464, 144, 64, 3, 2)
+#undef PF_PERSIST_CASE
     }
   }
   const TileCfg cfgs[6] = {{256, 128, 1, 1.0f, 0}, {128, 128, 2, 1.0f, 1}, {128, 96, 2, 0.97f, 2},

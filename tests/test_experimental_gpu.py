@@ -1,10 +1,10 @@
 """Opt-in checks of kernels that are NOT dispatched by default (skipped unless PF_TEST_EXPERIMENTAL=1).
 
-  PF_TEST_EXPERIMENTAL=1 PF_GEMM_PERSIST=1 python -m pytest tests/test_experimental_gpu.py -m gpu -q
+  PF_TEST_EXPERIMENTAL=1 python -m pytest tests/test_experimental_gpu.py -m gpu -q
 
-PF_GEMM_PERSIST (1 = automatic channel tile, or 128 / 96 / 64) routes every bf16 1x1 / linear layer with
-Cin % 64 == 0, Cin >= 128, Cout >= 64 and >= 1024 rows to the persistent GEMM (`gemm_persist_kernel`,
-patchfusion_amd/csrc/igemm.hip); the environment variable is read once per process, hence the separate invocation.
+PF_GEMM_PERSIST (read per call: 1 = shape chosen by the makespan model, or a forced shape code 128128 / 12896 / 12864 /
+144128 / 14464 = BMxBN) routes every bf16 1x1 / linear layer with Cin % 64 == 0, Cin >= 128, Cout >= 64 and >= 1024
+rows to the persistent GEMM (`gemm_persist_kernel`, patchfusion_amd/csrc/igemm.hip).
 """
 import os
 
@@ -13,6 +13,17 @@ import torch
 
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(os.environ.get("PF_TEST_EXPERIMENTAL") != "1", reason="experimental kernels are opt-in")]
+
+
+@pytest.fixture(params=["1", "128128", "12896", "12864", "144128", "14464"])
+def persist_mode(request):
+    old = os.environ.get("PF_GEMM_PERSIST")
+    os.environ["PF_GEMM_PERSIST"] = request.param
+    yield request.param
+    if old is None:
+        del os.environ["PF_GEMM_PERSIST"]
+    else:
+        os.environ["PF_GEMM_PERSIST"] = old
 
 
 @pytest.mark.parametrize("case", [
@@ -25,15 +36,14 @@ pytestmark = [pytest.mark.gpu,
     (2, 40, 52, 128, 64, dict(relu_in=True, res=True, res2=True)),
     (1, 33, 47, 192, 80, dict(act="gelu", out_f32=True)),
 ])
-def test_persistent_gemm_matches_reference(case):
+def test_persistent_gemm_matches_reference(case, persist_mode):
     from tests import op_checks
-    assert int(os.environ.get("PF_GEMM_PERSIST", "0")) > 0, "set PF_GEMM_PERSIST to route the GEMMs to the persistent kernel"
     B, H, W, cin, cout, kw = case
     err, tol, name = op_checks._conv_case(torch.bfloat16, B, H, W, cin, cout, 1, seed=41, **kw)
     assert err <= tol, (name, err)
 
 
-def test_persistent_gemm_is_deterministic():
+def test_persistent_gemm_is_deterministic(persist_mode):
     import hashlib
     from patchfusion_amd import packing as pk
     from patchfusion_amd.hip_ops import ops

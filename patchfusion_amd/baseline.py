@@ -88,5 +88,5 @@ class BaselinePretrain(PatchFusion):
             ops.crop_resize(img, bt[s:e], crops)
             depth, _ = nets["branch"].forward(ops, crops)
             ops.copy_plane(depth.unsqueeze(1), preds[s:e])
-        avg = self._stitch(preds, tiles, tile_cfg)
+        avg = self._stitch(preds, tiles, tile_cfg, cai_mode)
         return avg.unsqueeze(0).unsqueeze(0), {}

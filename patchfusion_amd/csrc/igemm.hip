@@ -17,6 +17,7 @@
 // f32 : v_mfma_f32_16x16x4_f32 (exact f32 FMA chain). A lane reads one float4 at slot g; element e of
 //       it feeds MFMA e, i.e. MFMA e contracts k in {4g+e}: a k-permutation applied identically to
 //       both operands, which leaves the sum unchanged.
+#include <atomic>
 #include "pf_common.h"
 #include "../../include/pf_hip.h"
 
@@ -542,6 +543,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_persist_kernel(const pf_con
   }
 }
 
+
+// ---- launch helpers.  The >64 KiB dynamic-LDS opt-in is a per-DEVICE function attribute: one bit per device ordinal,
+// set atomically, so a second GPU in the same process (or a second host thread) gets its own hipFuncSetAttribute.
+// The launch status is captured ONCE (hipGetLastError clears it) and kept for pf_conv's error message. ----
+thread_local hipError_t g_launch_status = hipSuccess;
+inline void ensure_dynamic_lds(const void* kern, int smem, std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
+    hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    done.fetch_or(bit, std::memory_order_release);
+  }
+}
+inline int launch_status() {
+  g_launch_status = hipGetLastError();
+  return g_launch_status == hipSuccess ? PF_OK : PF_ERR_LAUNCH;
+}
+
 // candidate shapes of the persistent GEMM: {BM, BN, WM, WN}; resident blocks per CU follow from the 160 KiB of LDS
 template <int BM, int BN, int WM, int WN>
 struct PersistCfg {
@@ -554,17 +574,14 @@ template <int BM, int BN, int WM, int WN, bool RELU_IN>
 int launch_persist(const pf_conv_params& p, hipStream_t st) {
   using C = PersistCfg<BM, BN, WM, WN>;
   constexpr int smem = C::smem;
-  static bool attr_set = false;
+  static std::atomic<unsigned long long> attr_done{0};
   auto kern = gemm_persist_kernel<BM, BN, WM, WN, RELU_IN>;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+  ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
   const long M = (long)p.B * p.OH * p.OW;
   const long tiles = ((M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
   const long slots = 256L * C::occ;                      // resident blocks
   hipLaunchKernelGGL(kern, dim3((unsigned)(tiles < slots ? tiles : slots)), dim3(64 * WM * WN), smem, st, p);
-  return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_LAUNCH;
+  return launch_status();
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -783,16 +800,13 @@ __global__ __launch_bounds__(512) void conv_igemm_big_kernel(const pf_conv_param
 template <bool RELU_IN>
 int launch_big(const pf_conv_params& p, hipStream_t st) {
   constexpr int smem = 3 * (256 + 128) * 128;
-  static bool attr_set = false;
+  static std::atomic<unsigned long long> attr_done{0};
   auto kern = conv_igemm_big_kernel<RELU_IN>;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+  ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
   const long M = (long)p.B * p.OH * p.OW;
   const long mt = (M + 255) / 256, nt = (p.Cout + 127) / 128;
   hipLaunchKernelGGL(kern, dim3((unsigned)(mt * nt)), dim3(512), smem, st, p);
-  return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_LAUNCH;
+  return launch_status();
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1224,16 +1238,13 @@ template <int WN, int FM, int FN, bool RELU_IN>
 int launch_halo(const pf_conv_params& p, hipStream_t st) {
   constexpr int BN = WN * 32 * FN;
   constexpr int smem = 2 * 40960 + 2 * 3 * BN * 64;
-  static bool attr_set = false;
+  static std::atomic<unsigned long long> attr_done{0};
   auto kern = conv3x3_halo_kernel<WN, FM, FN, RELU_IN>;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+  ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
   const long tiles = (long)p.B * ((p.H + 15) / 16) * ((p.W + 31) / 32);
   const long nt = (p.Cout + BN - 1) / BN;
   hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * nt)), dim3(512), smem, st, p);
-  return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_LAUNCH;
+  return launch_status();
 }
 
 thread_local char g_err[256] = {0};
@@ -1241,16 +1252,13 @@ thread_local char g_err[256] = {0};
 template <typename T, int BM, int BN, int WM, int WN, bool RELU_IN>
 int launch_cfg2(const pf_conv_params& p, hipStream_t st) {
   constexpr int smem = 2 * (BM + ((BN + 31) / 32) * 32) * 128;
-  static bool attr_set = false;
+  static std::atomic<unsigned long long> attr_done{0};
   auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, RELU_IN>;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+  ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
   const long M = (long)p.B * p.OH * p.OW;
   const long mt = (M + BM - 1) / BM, nt = (p.Cout + BN - 1) / BN;
   hipLaunchKernelGGL(kern, dim3((unsigned)(mt * nt)), dim3(256), smem, st, p);
-  return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_LAUNCH;
+  return launch_status();
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
@@ -1395,7 +1403,7 @@ extern "C" int pf_conv(const pf_conv_params* p, void* stream) {
   if (rc) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   rc = p->dtype == PF_DTYPE_BF16 ? dispatch<bf16_t>(*p, st) : dispatch<float>(*p, st);
-  if (rc) snprintf(g_err, sizeof(g_err), "pf_conv: launch failed: %s", hipGetErrorString(hipGetLastError()));
+  if (rc) snprintf(g_err, sizeof(g_err), "pf_conv: launch failed: %s", hipGetErrorString(g_launch_status));
   return rc;
 }
 

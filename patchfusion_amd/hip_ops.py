@@ -31,6 +31,11 @@ def _p(t):
         return None
     if not t.is_cuda:
         raise _lib.PfError("patchfusion_amd.hip_ops: tensor is not on the GPU (there is no CPU path)")
+    if t.device.index != torch.cuda.current_device():
+        # kernels are launched on torch's CURRENT device/stream; a tensor of another GPU would be accessed through the
+        # wrong context (and the >64 KiB LDS opt-in is per device): make the mismatch loud instead
+        raise _lib.PfError(f"patchfusion_amd.hip_ops: tensor lives on cuda:{t.device.index} but the current device is "
+                           f"cuda:{torch.cuda.current_device()} (wrap the call in torch.cuda.device(...))")
     return C.c_void_p(t.data_ptr())
 
 

@@ -13,9 +13,17 @@ What is mirrored:
     ValueError for bin_centers_type -- same exception types as the reference.
 Out of scope (north star is inference): ``mode='train'`` raises NotImplementedError.
 
-Multi-GPU: when torch.distributed is initialised and ``shard_patches=True`` the tiles of ONE image
-are sharded over ranks (contiguous chunks) and the per-patch depths are all-gathered over RCCL.
+Multi-GPU: two axes, like the reference leaves them.
+  * image-level data parallelism (tools/test.py:218-239: DDP + DistributedSampler, every rank holds a
+    DIFFERENT image) is the DEFAULT -- the module does no communication at all;
+  * single-image tile sharding (BASELINE configs[3]/[4]) is an explicit opt-in: ``shard_patches=True`` in the
+    constructor, ``shard_patches=True`` in the model config, or ``PF_SHARD_PATCHES=1``.  Then the tiles of ONE
+    image are sharded over ranks (contiguous chunks) and the per-patch depths are all-gathered over RCCL.
+    Before sharding every forward verifies with one tiny all_reduce that all ranks really hold the same
+    image (and, for ``r<N>``, rank 0's random tile schedule is broadcast) -- a mismatch raises on every rank
+    instead of silently stitching tiles of different images.
 """
+import os as _os
 from collections import OrderedDict
 from contextlib import nullcontext as _nullcontext
 
@@ -35,6 +43,17 @@ except Exception:  # pragma: no cover
 
 _DTYPES = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16,
            torch.float32: torch.float32, torch.bfloat16: torch.bfloat16}
+
+
+def _is_mmengine_configdict(config):
+    """isinstance(config, mmengine.ConfigDict) without requiring mmengine (the reference's test, patchfusion.py:64)."""
+    try:
+        from mmengine import ConfigDict
+        if isinstance(config, ConfigDict):
+            return True
+    except Exception:
+        pass
+    return any(c.__name__ == "ConfigDict" for c in type(config).__mro__)
 
 
 class Resizer:
@@ -85,11 +104,20 @@ def _build_param_tree(root, spec):
 
 
 class PatchFusion(nn.Module, PyTorchModelHubMixin):
-    def __init__(self, config, compute_dtype=None, ops=None, shard_patches=True):
+    def __init__(self, config, compute_dtype=None, ops=None, shard_patches=None):
         nn.Module.__init__(self)
+        # patchfusion.py:64-78: an mmengine ConfigDict (tools/test.py, tools/train.py) forces load_branch=True; any
+        # other mapping (the HF `from_pretrained` path hands over a plain dict read from config.json, which was
+        # SAVED with load_branch=true and local pretrain_model paths) forces load_branch=False.
+        from_mmengine = _is_mmengine_configdict(config)
         if hasattr(config, "to_dict") and not isinstance(config, AttrDict):
             config = config.to_dict()
         config = AttrDict(dict(config))
+        config["load_branch"] = bool(from_mmengine)
+        if not from_mmengine:
+            for br in ("coarse_branch", "fine_branch"):
+                if isinstance(config.get(br), dict):
+                    config[br]["pretrained_resource"] = None
         self.config = config
         self.min_depth, self.max_depth = config.min_depth, config.max_depth
         self.patch_process_shape = tuple(config.patch_process_shape)
@@ -113,9 +141,10 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
         _build_param_tree(self, self.spec)
         self.consistency_training = False
         self.compute_dtype = _DTYPES[compute_dtype or config.get("compute_dtype", "fp32")]
-        self.shard_patches = shard_patches
+        if shard_patches is None:
+            shard_patches = bool(config.get("shard_patches", False)) or _os.environ.get("PF_SHARD_PATCHES", "0") == "1"
+        self.shard_patches = bool(shard_patches)
         self._ops = ops
-        import os as _os
         self.overlap_coarse = bool(config.get("overlap_coarse", True)) and _os.environ.get("PF_OVERLAP", "1") != "0"
         self.overlap_batches = bool(config.get("overlap_batches", True)) and _os.environ.get("PF_OVERLAP_BATCHES", "1") != "0"
         self._side_stream = None
@@ -123,11 +152,21 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
         self.n_streams = int(_os.environ.get("PF_STREAMS", config.get("n_streams", 2)))
         self._engine = None
         self._coarse_state = None
-        if config.get("load_branch", False) and config.get("pretrain_model"):
+        if config.load_branch:
+            # patchfusion.py:105-109: each branch checkpoint is loaded with strict=True into its own sub-module
             for prefix, path in zip(("coarse_branch.", "fine_branch."), config.pretrain_model):
-                if path:
-                    sd = torch.load(path, map_location='cpu')['model_state_dict']
-                    self.load_state_dict({prefix + k: v for k, v in sd.items()}, strict=False)
+                self._load_branch(prefix, torch.load(path, map_location='cpu')['model_state_dict'])
+
+    def _load_branch(self, prefix, branch_sd):
+        """``self.<branch>.load_state_dict(sd, strict=True)`` of the reference: missing / unexpected keys raise."""
+        want = [k[len(prefix):] for k in self.spec if k.startswith(prefix)]
+        missing = [k for k in want if k not in branch_sd]
+        unexpected = [k for k in branch_sd if k not in set(want)]
+        if missing or unexpected:
+            raise RuntimeError(f"Error(s) in loading state_dict for {prefix[:-1]}: Missing key(s): {missing[:8]}"
+                               f"{' ...' if len(missing) > 8 else ''}; Unexpected key(s): {unexpected[:8]}"
+                               f"{' ...' if len(unexpected) > 8 else ''}")
+        return self.load_state_dict({prefix + k: v for k, v in branch_sd.items()}, strict=False)
 
     # ------------------------------------------------------------------ reference helper surface
     def prepare_tile_cfg(self, image_raw_shape, patch_split_num):
@@ -247,15 +286,50 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
             self._table_cache[key] = hit
         return hit
 
+    def _sharding(self):
+        """(rank, world) of the single-image tile sharding; (0, 1) unless it was explicitly requested."""
+        if self.shard_patches and torch.distributed.is_available() and torch.distributed.is_initialized():
+            return torch.distributed.get_rank(), torch.distributed.get_world_size()
+        return 0, 1
+
+    def _same_image_token(self, image_lr, image_hr):
+        """Tile sharding is only meaningful when every rank holds the SAME image (tools/test.py's DistributedSampler
+        gives every rank a different one).  One all_reduce(MAX) of [c, -c] for a 4-number checksum of the inputs
+        proves equality (max == min on every component); a mismatch raises on ALL ranks, so nobody is left waiting in
+        the later all_gather."""
+        import torch.distributed as dist
+        c = torch.stack([image_hr.float().sum(), image_hr.float().abs().max(), image_hr.float()[..., ::97].sum(),
+                         image_lr.float().sum()]).double()
+        c = torch.cat([c, c.new_full((1,), float(image_hr.shape[-2])), c.new_full((1,), float(image_hr.shape[-1]))])  # no H2D copy
+        v = torch.cat([c, -c])
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        n = c.numel()
+        return (v[:n] == -v[n:]).all()      # device bool; read (one host sync) only after all tile kernels are queued
+
+    @staticmethod
+    def _raise_if_images_differ(same, world):
+        if same is not None and not bool(same):
+            raise RuntimeError(
+                "PatchFusion(shard_patches=True): the ranks hold DIFFERENT images -- tile sharding needs the same image on "
+                f"all {world} ranks.  For image-level data parallelism (tools/test.py / dist_test.sh with a "
+                "DistributedSampler) leave shard_patches off (the default).")
+
+    @staticmethod
+    def _broadcast_schedule(tiles, world):
+        """r<N>: tile positions come from python's process-global `random`; every rank must paste the SAME tiles,
+        so rank 0's schedule is authoritative (a few hundred ints)."""
+        import torch.distributed as dist
+        box = [tiles]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
     @torch.no_grad()
-    def _predict_tiles(self, image_hr, tiles, tile_cfg, process_num, coarse_ready=None):
+    def _predict_tiles(self, image_hr, tiles, tile_cfg, process_num, coarse_ready=None, same_image=None):
         """Per-tile depth [P,h,w] f32 for this rank's shard (all tiles when not distributed)."""
         ops, dev = self.ops, self._device
         ph, pw = self.patch_process_shape
         n = len(tiles)
-        rank, world = 0, 1
-        if self.shard_patches and torch.distributed.is_available() and torch.distributed.is_initialized():
-            rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
+        rank, world = self._sharding()
         lo, hi = tiling.shard_range(n, rank, world)
         preds = ops.empty((n, ph, pw), torch.float32, dev)
         img = image_hr[0].contiguous().float()
@@ -291,6 +365,7 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
             main.wait_stream(a)
         if world > 1:
             from .dist import all_gather_shards
+            self._raise_if_images_differ(same_image, world)   # every rank sees the same verdict -> all raise or none
             preds = all_gather_shards(preds, n, world)
         return preds
 
@@ -301,7 +376,7 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
             self._table_cache[('paste', paste)] = hit
         return hit
 
-    def _stitch(self, preds, tiles, tile_cfg):
+    def _stitch(self, preds, tiles, tile_cfg, cai_mode='m1'):
         ops, dev = self.ops, self._device
         ph, pw = self.patch_process_shape
         RH, RW = tile_cfg['patch_reensemble_shape']
@@ -327,6 +402,13 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
                     raw_mask = self._mask(tile_cfg['patch_raw_shape'])
                     resized = True
                 ops.stitch_update(avg, count, preds[i], raw_mask, t['paste'][0], t['paste'][1])
+        if cai_mode[0] == 'r' and not resized:
+            # r<N> that draws zero random tiles: the reference still runs avg_depth_map.resize(image_raw_shape)
+            # (patchfusion.py:436-438, baseline_pretrain.py:401-403) -> nearest resize of the map to the raw resolution
+            H, W = tile_cfg['image_raw_shape']
+            a2 = ops.empty((H, W), torch.float32, dev)
+            ops.resize_nearest_f32(avg, a2)
+            avg = a2
         return avg
 
     # ------------------------------------------------------------------ forward
@@ -355,13 +437,13 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
         else:
             self._coarse(image_lr)
         tiles = tiling.tile_schedule(tile_cfg, self.patch_process_shape, cai_mode, process_num)
-        preds = self._predict_tiles(image_hr, tiles, tile_cfg, process_num, coarse_ready)
-        avg = self._stitch(preds, tiles, tile_cfg)
-        if cai_mode[0] == 'r' and not any(t['phase'] == 'random' for t in tiles):
-            # r<N> with N < process_num: the reference still resizes the map to the raw resolution
-            H, W = tile_cfg['image_raw_shape']
-            a2 = self.ops.empty((H, W), torch.float32, self._device)
-            self.ops.resize_nearest_f32(avg, a2)
-            avg = a2
+        _, world = self._sharding()
+        same = None
+        if world > 1:
+            same = self._same_image_token(image_lr, image_hr)
+            if cai_mode[0] == 'r':
+                tiles = self._broadcast_schedule(tiles, world)
+        preds = self._predict_tiles(image_hr, tiles, tile_cfg, process_num, coarse_ready, same)
+        avg = self._stitch(preds, tiles, tile_cfg, cai_mode)
         depth = avg.unsqueeze(0).unsqueeze(0)
         return depth, {'rgb': image_lr, 'depth_pred': depth, 'depth_gt': depth_gt}

@@ -25,18 +25,35 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, mode, out_dir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    torch.set_num_threads(2)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _model(shard):
     from patchfusion_amd.model import PatchFusion
     from tests.fake_ops import ops as fake_ops
     cfg = make_config(*TINY)
+    if shard == "config":                       # the mmengine-config route: MODELS.build(cfg.model) cannot pass kwargs
+        cfg["shard_patches"] = True
     sd = synthetic_state_dict(patchfusion_spec(cfg), 0)
-    m = PatchFusion(cfg, compute_dtype="fp32", ops=fake_ops).eval()
+    m = PatchFusion(cfg, compute_dtype="fp32", ops=fake_ops, **({"shard_patches": True} if shard == "kwarg" else {})).eval()
     m.load_state_dict(sd, strict=True)
-    img = torch.rand(1, 3, *TINY[2], generator=torch.Generator().manual_seed(1234))
-    random.seed(5621)
+    return m
+
+
+def _image(seed):
+    return torch.rand(1, 3, *TINY[2], generator=torch.Generator().manual_seed(seed))
+
+
+def _init(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _worker_shard(rank, world, port, mode, shard, out_dir):
+    """single-image tile sharding (explicit opt-in): both ranks hold the SAME image."""
+    _init(rank, world, port)
+    m = _model(shard)
+    img = _image(1234)
+    # r-mode: the ranks deliberately start from DIFFERENT python-random states; rank 0's schedule must win
+    random.seed(5621 if rank == 0 else 777 + rank)
     # tools/test.py:221 wraps the model in DistributedDataParallel before Tester.run calls it
     ddp = torch.nn.parallel.DistributedDataParallel(m)
     with torch.no_grad():
@@ -45,14 +62,86 @@ def _worker(rank, world, port, mode, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["m2"])
-def test_two_rank_patch_sharding_matches_golden(tmp_path, golden_dir, mode):
+def _worker_image_dp(rank, world, port, n_images, out_dir):
+    """the reference's own multi-GPU evaluation (tools/test.py:218-239, tester.py:46-64): DDP + DistributedSampler,
+    every rank a DIFFERENT image, default-constructed model -> no tile sharding, no collective, correct maps.  With an odd
+    image count the sampler pads by repeating image 0; nothing may hang."""
+    from torch.utils.data import DataLoader, Dataset
+    from torch.utils.data.distributed import DistributedSampler
+
+    class Images(Dataset):
+        def __len__(self):
+            return n_images
+
+        def __getitem__(self, i):
+            return dict(idx=i, image_hr=_image(100 + i)[0])
+
+    _init(rank, world, port)
+    m = _model(None)
+    assert m.shard_patches is False
+    ddp = torch.nn.parallel.DistributedDataParallel(m)
+    ds = Images()
+    loader = DataLoader(ds, batch_size=1, sampler=DistributedSampler(ds, shuffle=False))
+    for batch in loader:
+        hr = batch["image_hr"]
+        with torch.no_grad():
+            d, _ = ddp(mode="infer", image_lr=m.resizer(hr), image_hr=hr, cai_mode="m1", process_num=2)
+        np.save(os.path.join(out_dir, f"img{int(batch['idx'])}_rank{rank}.npy"), d.numpy())
+    dist.destroy_process_group()
+
+
+def _worker_mismatch(rank, world, port, out_dir):
+    """opt-in sharding but the ranks hold different images: every rank must raise (nobody hangs in the gather)."""
+    _init(rank, world, port)
+    m = _model("kwarg")
+    img = _image(1234 + rank)
+    try:
+        with torch.no_grad():
+            m(mode="infer", image_lr=m.resizer(img), image_hr=img, cai_mode="m1", process_num=2)
+        msg = "no error"
+    except RuntimeError as e:
+        msg = str(e)
+    open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write(msg)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,shard", [("m2", "kwarg"), ("m1", "config"), ("r4", "kwarg")])
+def test_two_rank_patch_sharding_matches_golden(tmp_path, golden_dir, mode, shard):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, mode, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker_shard, args=(2, port, mode, shard, str(tmp_path)), nprocs=2, join=True)
     a, b = np.load(tmp_path / "rank0.npy"), np.load(tmp_path / "rank1.npy")
     assert np.array_equal(a, b)                                   # every rank stitches the same map
-    ref = np.load(os.path.join(golden_dir, "tiny_vits.npz"))[f"depth_{mode}"]
-    assert np.abs(a[0, 0] - ref).max() < 2e-5
+    ref = np.load(os.path.join(golden_dir, "tiny_vits.npz"))[f"depth_{mode}"]   # r4 golden: random.seed(5621) = rank 0's state
+    assert a[0, 0].shape == ref.shape and np.abs(a[0, 0] - ref).max() < 2e-5
+
+
+@pytest.mark.parametrize("n_images", [2, 3])
+def test_image_level_data_parallel_like_tools_test_py(tmp_path, n_images):
+    port = _free_port()
+    mp.spawn(_worker_image_dp, args=(2, port, n_images, str(tmp_path)), nprocs=2, join=True)
+    single = _model(None)
+    for i in range(n_images):
+        files = sorted(tmp_path.glob(f"img{i}_rank*.npy"))
+        assert files, f"image {i} was never evaluated"
+        img = _image(100 + i)
+        with torch.no_grad():
+            ref, _ = single(mode="infer", image_lr=single.resizer(img), image_hr=img, cai_mode="m1", process_num=2)
+        for f in files:
+            # each rank's map == the single-process map of ITS image (thread count differs -> summation order, not bits)
+            assert np.abs(np.load(f) - ref.numpy()).max() < 2e-5, f.name
+
+
+def test_sharding_with_different_images_raises_on_every_rank(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker_mismatch, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert "DIFFERENT images" in (tmp_path / f"rank{r}.txt").read_text()
+
+
+def test_sharding_is_off_by_default_and_env_opt_in(monkeypatch):
+    assert _model(None).shard_patches is False
+    monkeypatch.setenv("PF_SHARD_PATCHES", "1")
+    assert _model(None).shard_patches is True
 
 
 def test_shard_range_partitions_exactly():

@@ -6,18 +6,28 @@
          bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path (coarse branch + G2L + per-tile fine branch + guided fusion + stitch)
-over one synthetic 2160x3840 image that is already resident in HBM.  Weak scaling: every GPU processes 16
-tiles per step -- at N GPUs the image is split into 16*N tiles (4x4, 4x8, 8x8, 8x16) that are sharded over
-the ranks (coarse branch + G2L replicated, no communication) and the per-tile depths are all-gathered over
-RCCL before every rank stitches.  value = tiles processed by all ranks / max-over-ranks wall time.
+over one synthetic 2160x3840 image that is already resident in HBM.
+
+HEADLINE PRECISION = the reference's: float32 end to end (`dtype: "f32"`, exact mode: f32 storage, f32 MFMA
+v_mfma_f32_16x16x4_f32 = an fma chain, parity bar 2e-4 in depth units against the reference's own outputs).
+The fast mode (bf16 storage / bf16 MFMA, f32 accumulation and f32 metric-bins head) is timed on the same image with
+the same K/W and reported in the secondary object `"bf16"` TOGETHER WITH ITS MEASURED ERROR against the f32 map of
+the same run (max / p99 / mean |delta| in depth units) -- it is never the headline `value`.
+
+Tiles per step: N=1 4x4 (configs[2], 16 tiles), N=2 4x8 (32), N=4 8x8 (64) -- 16 tiles per GPU, weak scaling --
+and N=8 8x8 = 64 tiles sharded 8-way, 8 per GPU (BASELINE.json configs[3]).  The tiles of the image are sharded over
+the ranks (explicit opt-in shard_patches=True; coarse branch + G2L replicated, no communication) and the per-tile
+depths are all-gathered over RCCL before every rank stitches.  value = tiles of the image / max-over-ranks wall time.
 
 Rank 0 prints ONE JSON line (contract in the task statement) including
-  roofline     : the dominant kernel (implicit-GEMM 3x3 conv 544->544 @ 8x392x518, the largest single op of
-                 the fusion U-Net) timed live with HIP events on its launch stream, vs the dense MFMA peak
-  cpu_baseline : the oracle (CPU port of the reference, oracle/pf_oracle.py) timed on the host cores for a
-                 bounded sample (one tile = fine branch + fusion) of the same workload  [N=1, rank 0 only]
+  roofline     : the dominant kernel of the headline mode (3x3 conv 544->544 @ 8x392x518, the largest single op of
+                 the fusion U-Net) timed live with HIP events on its launch stream, vs the dense MFMA peak of the dtype
+  bf16         : {value, ms_per_step, err{...}, roofline{...}}  (N=1 only)
+  cpu_baseline : kind "reference" = the reference's own PatchFusion (oracle/ref_shim.py) when /root/reference exists
+                 on the box, else kind "port" = the oracle (oracle/pf_oracle.py); bounded sample, N=1 rank 0 only
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -28,9 +38,9 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SPLITS = {1: (4, 4), 2: (4, 8), 4: (8, 8), 8: (8, 16)}
+SPLITS = {1: (4, 4), 2: (4, 8), 4: (8, 8), 8: (8, 8)}
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # MI355X_MICROARCH.md: dense MFMA peaks
-
+DTYPE_NAME = {"fp32": "f32", "bf16": "bf16"}
 
 T0 = time.time()
 
@@ -44,11 +54,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--dtype", default=os.environ.get("PF_BENCH_DTYPE", "bf16"), choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default=os.environ.get("PF_BENCH_DTYPE", "fp32"), choices=["bf16", "fp32"],
+                    help="headline mode (default fp32 = the reference's precision)")
     ap.add_argument("--encoder", default="vitl")
     ap.add_argument("--process-num", type=int, default=8)
+    ap.add_argument("--split", default=None, help="override the tile grid, e.g. 8x16 (kernel / scaling experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary bf16 leg")
     ap.add_argument("--roofline-only", action="store_true", help="only time the dominant kernel (kernel tuning aid)")
     ap.add_argument("--gemm-sweep", action="store_true", help="time the ViT-L linear layers / other shapes (kernel tuning aid)")
     args = ap.parse_args()
@@ -77,58 +90,85 @@ def main():
     from patchfusion_amd.spec import patchfusion_spec, synthetic_state_dict
 
     raw = (2160, 3840)
-    split = SPLITS.get(N, (4, 4))
+    split = tuple(int(v) for v in args.split.split("x")) if args.split else SPLITS.get(N, (4, 4))
     cfg = make_config(args.encoder, (392, 518), raw, split)
     sd = synthetic_state_dict(patchfusion_spec(cfg), 0)
-    model = PatchFusion(cfg, compute_dtype=args.dtype).eval()
-    model.load_state_dict(sd, strict=True)
-    model = model.to(dev)
-    log("model built and on device")
     img = torch.rand(1, 3, *raw, generator=torch.Generator().manual_seed(1234)).to(dev)
-    lr = model.resizer(img)
     P = split[0] * split[1]
-
-    def step():
-        d, _ = model(mode="infer", image_lr=lr, image_hr=img, cai_mode="m1", process_num=args.process_num)
-        return d
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step()
-        torch.cuda.synchronize()
-        log(f"warmup step {i} done")
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    log(f"timed {args.steps} steps: {dt:.3f}s")
+    def run_mode(dtype):
+        """W untimed + K timed steps of the whole hot path in `dtype`; -> (seconds for K steps, last depth map)."""
+        model = PatchFusion(cfg, compute_dtype=dtype, shard_patches=world > 1).eval()
+        model.load_state_dict(sd, strict=True)
+        model = model.to(dev)
+        lr = model.resizer(img)
+
+        def step():
+            d, _ = model(mode="infer", image_lr=lr, image_hr=img, cai_mode="m1", process_num=args.process_num)
+            return d
+
+        d = None
+        for i in range(args.warmup):
+            d = step()
+            torch.cuda.synchronize()
+            log(f"{dtype}: warmup step {i} done")
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            d = step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        log(f"{dtype}: timed {args.steps} steps: {dt:.3f}s")
+        d = d.float().clone()
+        del model
+        torch.cuda.empty_cache()
+        return dt, d
+
+    dt, depth = run_mode(args.dtype)
     ms = dt / args.steps * 1e3
     value = P * args.steps / dt
-
+    per_gpu = P // N
+    if N <= 4:
+        scaling, which = "weak", f"BASELINE.json configs[2] at N=1; {per_gpu} tiles per GPU"
+    else:
+        scaling, which = "strong", "BASELINE.json configs[3]: P=64 tiles sharded 8-way, 8 per GPU (same image and tile count as N=4)"
     out = {
-        "metric": "patches/sec (DepthAnything-ViT-L PatchFusion, 4K image, P=16 tiles per GPU)",
+        "metric": "patches/sec (DepthAnything-ViT-L PatchFusion, 4K image, P=16 tiles at N=1)",
         "value": round(value, 3), "unit": "patches/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms, 3), "ms_per_4k_image": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "ms_per_step": round(ms, 3), "ms_per_4k_image": round(ms, 3), "higher_is_better": True, "scaling": scaling,
+        "vs_baseline": None, "dtype": DTYPE_NAME[args.dtype], "data": "synthetic",
         "config": {"workload": f"Depth-Anything-{args.encoder}14 PatchFusion, 2160x3840 synthetic RGB, "
-                               f"{split[0]}x{split[1]} regular tiling (cai_mode m1, {P} tiles = 16 per GPU), process_num={args.process_num}, "
-                               "random-init weights (BASELINE.json configs[2] at N=1)",
+                               f"{split[0]}x{split[1]} regular tiling (cai_mode m1, {P} tiles), process_num={args.process_num}, "
+                               f"random-init weights ({which})",
+                   "precision": "float32 storage + f32 MFMA (exact mode = the reference's precision)" if args.dtype == "fp32"
+                                else "bf16 storage + bf16 MFMA, f32 accumulation, f32 metric-bins head",
                    "parallelism": f"patch-sharded x{N}, coarse+G2L replicated, RCCL all_gather of tile depths" if N > 1 else "single GPU"},
     }
 
     if rank == 0 and not args.no_roofline:
         out["roofline"] = roofline(args.dtype, dev)
         log(f"roofline: {out['roofline']}")
+    if N == 1 and args.dtype == "fp32" and not args.no_secondary:
+        dt2, depth2 = run_mode("bf16")
+        diff = (depth2 - depth).abs().flatten()
+        sec = {"value": round(P * args.steps / dt2, 3), "unit": "patches/s", "ms_per_step": round(dt2 / args.steps * 1e3, 3),
+               "dtype": "bf16", "precision": "bf16 storage + bf16 MFMA, f32 accumulation, f32 metric-bins head",
+               "err_vs_f32_same_run": {"max_abs": float(diff.max()), "p99_abs": float(torch.quantile(diff[::7], 0.99)),
+                                       "mean_abs": float(diff.mean()), "depth_std": float(depth.std()),
+                                       "depth_min": float(depth.min()), "depth_max": float(depth.max()), "unit": "depth units"}}
+        if not args.no_roofline:
+            sec["roofline"] = roofline("bf16", dev)
+        out["bf16"] = sec
+        log(f"bf16 secondary: {sec}")
     if rank == 0 and N == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, sd, img.cpu())
     if rank == 0:
@@ -143,6 +183,7 @@ def gemm_sweep(dtype, dev):
     from patchfusion_amd.hip_ops import ops
     tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
     shapes = [("qkv", 8296, 1024, 3072, 1), ("proj", 8296, 1024, 1024, 1), ("fc1", 8296, 1024, 4096, 1), ("fc2", 8296, 4096, 1024, 1),
+              ("c544_544", 8 * 392 * 518, 544, 544, 3),
               ("up4_1", 8 * 224 * 296, 768, 768, 3), ("up4_2", 8 * 224 * 296, 768, 256, 3), ("c544_32", 8 * 392 * 518, 544, 32, 3),
               ("c64_32", 8 * 392 * 518, 64, 32, 3), ("c256_256_L4", 8 * 224 * 296, 512, 256, 3),
               ("up3_768_L3", 8 * 112 * 148, 768, 768, 3), ("up2_768_L2", 8 * 56 * 74, 768, 768, 3), ("up1_768_L1", 8 * 28 * 37, 768, 768, 3),
@@ -166,9 +207,19 @@ def gemm_sweep(dtype, dev):
         del x, y
 
 
+def kernel_source_sha():
+    h = hashlib.sha256()
+    for f in ("igemm.hip", "pf_common.h"):
+        with open(os.path.join(ROOT, "patchfusion_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
 def roofline(dtype, dev):
-    """Dominant kernel: conv_igemm_kernel on the fusion U-Net's 3x3 conv 544->544 @ [8,392,518] (vitl):
-    algorithmic FLOPs = 2 * 8*392*518 * 9*544 * 544 per launch."""
+    """Dominant kernel: the fusion U-Net's 3x3 conv 544->544 @ [8,392,518] (vitl), through the same pf_conv entry point
+    the engine uses: algorithmic FLOPs = 2 * 8*392*518 * 9*544 * 544 per launch.
+    `traffic` (HBM bytes per launch from the rocprofv3 PMC passes, which cannot run inside bench.py) is reported only when
+    profiles/r2_pmc_dominant_<dtype>.json was measured on EXACTLY this kernel source (sha of igemm.hip); otherwise null."""
     from patchfusion_amd import packing as pk
     from patchfusion_amd.hip_ops import ops
     tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
@@ -181,25 +232,37 @@ def roofline(dtype, dev):
     flops = 2.0 * B * H * W * 9 * C * C
     ach = flops / (ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[dtype]
-    traffic = None   # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside bench.py): profiles/r1_pmc_dominant_kernel.json
+    traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_pmc_dominant_kernel.json")) as f:
-            traffic = json.load(f)["derived"]["traffic_bytes"] if dtype == "bf16" else None
+        with open(os.path.join(ROOT, "profiles", f"r2_pmc_dominant_{dtype}.json")) as f:
+            j = json.load(f)
+        if j.get("kernel_source_sha") == kernel_source_sha():
+            traffic = j["derived"]["traffic_bytes"]
     except Exception:
         pass
-    return {"bound": "mfma", "kernel": "conv3x3_halo_kernel<2,4,3> (bf16) / conv_igemm_kernel (fp32): 3x3 544->544 @ 8x392x518, the GuidedFusion up-conv = largest op",
+    kern = {"bf16": "conv3x3_halo_kernel (bf16, v_mfma_f32_32x32x16_bf16)", "fp32": "conv3x3 f32 kernel (v_mfma_f32_16x16x4_f32)"}[dtype]
+    return {"bound": "mfma", "kernel": f"{kern}: 3x3 544->544 @ 8x392x518, the GuidedFusion up-conv = largest op",
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "traffic": traffic}
 
 
 def cpu_baseline(cfg, sd, img):
-    """The oracle (CPU restatement of the reference, kind 'port') on the host cores, bounded sample: ONE tile of
-    the same workload = fine branch + fusion_forward (4029.9 GFLOP, G2L hoisted like the engine does); the coarse
-    pass + G2L it needs are computed untimed.  Threads are capped at 64: with all 256 hardware threads of the
-    GPU box torch's CPU kernels oversubscribe (measured 108 s instead of ~5 s for one branch forward)."""
-    from oracle import pf_oracle
+    """CPU path on this box's host cores, bounded sample (threads capped at 64: with all 256 hardware threads of the GPU box
+    torch's CPU kernels oversubscribe -- measured 108 s instead of ~5 s for one branch forward).
+    kind 'reference': the reference's own `PatchFusion` (imported through oracle/ref_shim.py) on a 1x1-tile 4K image = ONE
+        patch through coarse branch + fine branch + fusion (the G2L stacks inside the fusion call, reference schedule);
+        only possible where /root/reference exists (not on the GPU box).
+    kind 'port': the oracle restatement, ONE tile of the same workload = fine branch + fusion_forward (4029.9 GFLOP, G2L
+        hoisted like the engine does); the coarse pass + G2L it needs are computed untimed."""
     cores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(cores)
+    from oracle import ref_shim
+    if ref_shim.reference_available():
+        try:
+            return _cpu_baseline_reference(cfg, sd, img, cores)
+        except Exception as e:      # a broken reference import must not lose the whole bench line
+            log(f"cpu baseline: reference path failed ({type(e).__name__}: {e}); falling back to the port")
+    from oracle import pf_oracle
     orc = pf_oracle.Oracle(cfg, sd)
     with torch.no_grad():
         lr = orc.resizer(img)
@@ -217,6 +280,26 @@ def cpu_baseline(cfg, sd, img):
     return {"value": round(1.0 / dt, 5), "unit": "patches/s", "cores": cores, "kind": "port",
             "sample": f"1 tile (fine branch + fusion, 4029.9 GFLOP, G2L hoisted) of the same DA-vitl 392x518 workload: "
                       f"{dt:.1f} s on {cores} threads"}
+
+
+def _cpu_baseline_reference(cfg, sd, img, cores):
+    from oracle import ref_shim
+    ref_shim.install_stubs()
+    c1 = dict(cfg)
+    c1["patch_split_num"] = (1, 1)
+    with ref_shim.in_reference_cwd():
+        PF = ref_shim.import_reference()
+        m = PF(c1).eval()
+        m.load_state_dict(sd, strict=True)
+        with torch.no_grad():
+            lr = m.resizer(img)
+            t0 = time.perf_counter()
+            m(mode="infer", image_lr=lr, image_hr=img, cai_mode="m1", process_num=1)
+            dt = time.perf_counter() - t0
+    log(f"cpu baseline: reference PatchFusion, one 1x1-tile image {dt:.1f}s on {cores} threads")
+    return {"value": round(1.0 / dt, 5), "unit": "patches/s", "cores": cores, "kind": "reference",
+            "sample": f"the reference's own PatchFusion.forward(mode='infer') on one 2160x3840 image with patch_split_num=(1,1): 1 patch "
+                      f"= coarse branch + fine branch + fusion incl. G2L (5373 GFLOP): {dt:.1f} s on {cores} threads"}
 
 
 if __name__ == "__main__":

@@ -44,6 +44,16 @@ class AttrDict(dict):
             return v
         return plain(self)
 
+    # the reference's `config` is a transformers.PretrainedConfig: tools/convert_huggingface.py:79 calls
+    # model.config.to_json_file(...) next to save_pretrained; keep that part of the surface
+    def to_json_string(self):
+        import json
+        return json.dumps(self.to_dict(), indent=2, sort_keys=True) + "\n"
+
+    def to_json_file(self, json_file_path):
+        with open(json_file_path, "w", encoding="utf-8") as f:
+            f.write(self.to_json_string())
+
 
 def pyramid_sizes(process_shape):
     """(h, w) of the six feature levels L5..L0 for a Depth-Anything branch at ``process_shape``

@@ -235,22 +235,43 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
     def coarse_forward(self, image_lr):
         """-> (coarse_prediction [1,1,h,w] f32, six coarse feature maps NCHW f32) like patchfusion.py:189-206"""
         st = self._coarse(image_lr)
-        return st["depth"], [self.ops.nhwc_to_nchw(f) for f in st["feats"]]
+        feats = [self.ops.nhwc_to_nchw(f) for f in st["feats"]]
+        st["handed_out"] = tuple(int(f.data_ptr()) for f in feats) + (int(st["depth"].data_ptr()),)
+        return st["depth"], feats
 
     def fine_forward(self, image_hr_crop):
         nets = self._ensure_engine()
         depth, feats = nets["fine"].forward(self.ops, image_hr_crop.contiguous().float())
         return depth.unsqueeze(1), [self.ops.nhwc_to_nchw(f) for f in feats]
 
+    def _state_from_tile_temp(self, tile_temp):
+        """The coarse state handed over by a caller that follows the reference protocol (patchfusion.py:410-414:
+        ``tile_temp = {'coarse_prediction': [1,1,h,w], 'coarse_features': [6 x NCHW]}``).  When these are the tensors the last
+        ``coarse_forward`` returned, the engine's own NHWC state (and the G2L maps derived from it) is reused; foreign
+        tensors are re-laid out (a permute -- no arithmetic) and the patch-invariant G2L stacks are recomputed from them."""
+        st = self._coarse_state
+        feats = tile_temp['coarse_features']
+        key = tuple(int(f.data_ptr()) for f in feats) + (int(tile_temp['coarse_prediction'].data_ptr()),)
+        if st is not None and st.get("handed_out") == key:
+            return st
+        nets = self._ensure_engine()
+        dev, dt = self._device, self.compute_dtype
+        nhwc = [f.detach().to(dev).permute(0, 2, 3, 1).contiguous().to(dt) for f in feats]
+        depth = tile_temp['coarse_prediction'].detach().to(device=dev, dtype=torch.float32).contiguous()
+        st = dict(depth=depth, feats=nhwc, g2l=nets["g2l"].forward(self.ops, nhwc), handed_out=key)
+        self._coarse_state = st
+        return st
+
     @torch.no_grad()
     def infer_forward(self, imgs_crop, bbox_feat_forward, tile_temp=None, coarse_temp_dict=None, taps=None):
         """fine branch + fusion for one batch of crops (patchfusion.py:343-356).  ``bbox_feat_forward``
-        [B,5] = (0, x1,y1,x2,y2) in process coordinates.  The coarse state of the current image is the
-        one produced by the last ``coarse_forward`` / ``forward`` call (``tile_temp`` / ``coarse_temp_dict``
-        are accepted for signature compatibility; the ROI crops are recomputed from the boxes in-kernel
-        instead of being materialised P times)."""
+        [B,5] = (0, x1,y1,x2,y2) in process coordinates.  ``tile_temp`` (``coarse_prediction`` + ``coarse_features``,
+        the way baseline_pretrain.py:293-307 passes them) selects the coarse state; without it the state of the last
+        ``coarse_forward`` / ``forward`` call is used.  ``coarse_temp_dict`` (the P-times repeated ROI crops of the
+        reference, patchfusion.py:240-257) is accepted and not read: the same ROI values are gathered from the coarse
+        maps inside the kernels from ``bbox_feat_forward`` -- identical numbers, no 1 GB transient."""
         nets = self._ensure_engine()
-        st = self._coarse_state
+        st = self._state_from_tile_temp(tile_temp) if tile_temp is not None else self._coarse_state
         assert st is not None, "run coarse_forward first"
         crops = imgs_crop.contiguous().float()
         rois = bbox_feat_forward

@@ -1273,7 +1273,7 @@ int g_force_small = -1;   // PF_IGEMM_SMALL=1 forces the 4-wave kernel everywher
 // each round costs ~ BM*BN*occ (all configs sustain a similar per-CU rate), scaled by a small
 // efficiency factor for the narrow tiles.  At the ViT sizes (8296 tokens x 1024 channels) this is the
 // difference between 2 half-empty rounds of 256x128 tiles and 1 full round of 128x96 tiles.
-struct TileCfg { int bm, bn, occ; float eff; int id; };
+template <typename T> int dispatch_generic(const pf_conv_params& p, hipStream_t st, bool allow_split);
 
 static bool force_halo() {
   const char* e = getenv("PF_HALO_FORCE");
@@ -1342,32 +1342,97 @@ int dispatch(const pf_conv_params& p, hipStream_t st) {
 #undef PF_PERSIST_CASE
     }
   }
-  const TileCfg cfgs[6] = {{256, 128, 1, 1.0f, 0}, {128, 128, 2, 1.0f, 1}, {128, 96, 2, 0.97f, 2},
-                           {128, 64, 3, 0.96f, 3}, {256, 32, 2, 0.75f, 4}, {256, 16, 2, 0.5f, 5}};
-  static int force_cfg = -2;
-  if (force_cfg == -2) {
-    const char* e = getenv("PF_IGEMM_CFG");
-    force_cfg = e ? atoi(e) : -1;
-  }
+  return dispatch_generic<T>(p, st, true);
+}
+
+// ---- generic implicit-GEMM path: tile choice + (f32) exact channel split -------------------------------------------
+// cost ~ makespan of `blocks` tiles on 256 CUs with `occ` co-resident blocks each (blocks / slots full rounds + a tail
+// round), times the per-round cost bm*bn*occ, over a small per-shape efficiency factor.
+struct TileCfg { int bm, bn, occ; float eff; int id; };
+static const TileCfg kCfgs[7] = {{256, 128, 1, 1.0f, 0}, {128, 128, 2, 1.0f, 1}, {128, 96, 2, 0.97f, 2},
+                                 {128, 64, 3, 0.96f, 3}, {256, 32, 2, 0.75f, 4}, {256, 16, 2, 0.5f, 5}, {64, 64, 4, 0.92f, 6}};
+
+template <typename T>
+static double cfg_cost(const TileCfg& c, long M, int cout) {
+  const long blocks = ((M + c.bm - 1) / c.bm) * ((cout + c.bn - 1) / c.bn);
+  return ((double)blocks / (256.0 * c.occ) + 1.0) * c.bm * c.bn * c.occ / c.eff;
+}
+
+template <typename T>
+static int best_cfg(const pf_conv_params& p, long M, int cout, double* cost_out) {
   int best = -1;
   double best_cost = 1e300;
-  for (int i = 0; i < 6; ++i) {
-    const TileCfg& c = cfgs[i];
-    if (c.id == 0 && (sizeof(T) != 2 || g_force_small == 1 || p.Cout < 96)) continue;   // big kernel: bf16 only
-    const long blocks = ((M + c.bm - 1) / c.bm) * ((p.Cout + c.bn - 1) / c.bn);
-    // makespan ~ (blocks / slots + one block of tail) * time per block
-    const double cost = ((double)blocks / (256.0 * c.occ) + 1.0) * c.bm * c.bn * c.occ / c.eff;
+  for (int i = 0; i < 7; ++i) {
+    const TileCfg& c = kCfgs[i];
+    if (c.id == 0 && (sizeof(T) != 2 || g_force_small == 1 || cout < 96)) continue;   // big kernel: bf16 only
+    if (c.id == 6 && sizeof(T) != 4) continue;                                        // 64x64: f32 granularity tile
+    const double cost = cfg_cost<T>(c, M, cout);
     if (cost < best_cost) { best_cost = cost; best = c.id; }
   }
-  if (force_cfg >= 0 && !(force_cfg == 0 && sizeof(T) != 2)) best = force_cfg;
-  switch (best) {
+  if (cost_out) *cost_out = best_cost;
+  return best;
+}
+
+template <typename T>
+int launch_generic(const pf_conv_params& p, hipStream_t st, int cfg) {
+  switch (cfg) {
     case 0: if constexpr (sizeof(T) == 2) return p.relu_in ? launch_big<true>(p, st) : launch_big<false>(p, st);
     case 1: return launch_cfg<T, 128, 128, 2, 2>(p, st);
     case 2: return launch_cfg<T, 128, 96, 2, 2>(p, st);
     case 3: return launch_cfg<T, 128, 64, 2, 2>(p, st);
     case 4: return launch_cfg<T, 256, 32, 4, 1>(p, st);
+    case 6: if constexpr (sizeof(T) == 4) return launch_cfg<T, 64, 64, 2, 2>(p, st);
     default: return launch_cfg<T, 256, 16, 4, 1>(p, st);
   }
+}
+
+// f32 only: the matrix pipe is the ONLY resource that matters at 1/16 of the bf16 rate, so padded output channels are
+// pure loss (544 = 6 x 96 - 32: 5.9 %).  Split the channel range into a body that a wide tile covers exactly and a
+// remainder launched with a narrower tile (544 = 5 x 96 + 64): two launches on the same stream, zero padded MFMAs.
+template <typename T>
+int dispatch_generic(const pf_conv_params& p, hipStream_t st, bool allow_split) {
+  const long M = (long)p.B * p.OH * p.OW;
+  static int force_cfg = -2, no_split = -1;
+  if (force_cfg == -2) {
+    const char* e = getenv("PF_IGEMM_CFG");
+    force_cfg = e ? atoi(e) : -1;
+    const char* e2 = getenv("PF_IGEMM_NOSPLIT");
+    no_split = e2 ? atoi(e2) : 0;
+  }
+  double cost_single;
+  int best = best_cfg<T>(p, M, p.Cout, &cost_single);
+  if (force_cfg >= 0 && !(force_cfg == 0 && sizeof(T) != 2) && !(force_cfg == 6 && sizeof(T) != 4)) return launch_generic<T>(p, st, force_cfg);
+  if constexpr (sizeof(T) == 4) {
+    if (allow_split && !no_split && p.shuffle <= 1 && p.Cout > 128) {
+      int split_at = 0, split_cfg = -1;
+      double split_cost = cost_single * 0.985;        // a second launch must buy at least 1.5 %
+      for (int i = 1; i <= 3; ++i) {                  // body tiles 128x128 / 128x96 / 128x64
+        const TileCfg& c = kCfgs[i];
+        const int body = (p.Cout / c.bn) * c.bn, rem = p.Cout - body;
+        if (body == 0 || rem == 0) continue;
+        double rem_cost;
+        best_cfg<T>(p, M, rem, &rem_cost);
+        const double cost = cfg_cost<T>(c, M, body) + rem_cost;
+        if (cost < split_cost) { split_cost = cost; split_at = body; split_cfg = c.id; }
+      }
+      if (split_at > 0) {
+        pf_conv_params a = p, b = p;
+        a.Cout = split_at;
+        b.Cout = p.Cout - split_at;
+        b.w = reinterpret_cast<const char*>(p.w) + (size_t)split_at * p.Kpad * sizeof(T);
+        b.w_rows = p.w_rows - split_at;
+        if (p.bias) b.bias = p.bias + split_at;
+        if (p.scale) b.scale = p.scale + split_at;
+        if (p.res) b.res = reinterpret_cast<const char*>(p.res) + (size_t)split_at * sizeof(T);
+        if (p.res2) b.res2 = reinterpret_cast<const char*>(p.res2) + (size_t)split_at * sizeof(T);
+        b.y = reinterpret_cast<char*>(p.y) + (size_t)split_at * sizeof(float);   // f32 path stores float
+        int rc = launch_generic<T>(a, st, split_cfg);
+        if (rc) return rc;
+        return dispatch_generic<T>(b, st, false);
+      }
+    }
+  }
+  return launch_generic<T>(p, st, best);
 }
 
 int validate(const pf_conv_params* p) {

@@ -176,6 +176,25 @@ def conv_big_gemm_gelu_k1024(dt):
     return _conv_case(dt, 1, 1, 3 * 1037, 1024, 4096, 1, act="gelu", seed=16)
 
 
+# ---- f32 exact channel split (544 = 5 x 96 + 64 etc.: body + remainder launches, dispatch_generic) and the 64x64 tile ----
+def conv_split_n272_res_views(dt):
+    return _conv_case(dt, 2, 20, 27, 64, 272, 3, pad=1, relu_in=True, res=True, res2=True, scale=True, y_extra=32, seed=31)
+
+
+def conv_split_gemm_n544_inplace(dt):
+    return _conv_case(dt, 1, 1, 1037, 256, 544, 1, scale=True, res=True, inplace=True, act="gelu", seed=32)
+
+
+def conv_gemm_vitl_linear_shape(dt):      # M = 8 x 1037 rows like the ViT-L linears (tile choice by the makespan model)
+    return _conv_case(dt, 1, 1, 8 * 1037, 256, 1024, 1, scale=True, res=True, seed=33)
+
+
+def conv_dominant_launch(dt):
+    """THE dominant launch at its real size: 3x3 544->544 @ 8x392x518 (GuidedFusion Upv1, guided_fusion_model.py:85-100)
+    against F.conv2d in fp32 on the same (dtype-rounded) operands."""
+    return _conv_case(dt, 8, 392, 518, 544, 544, 3, pad=1, act="relu", seed=34)
+
+
 def conv_big_transpose(dt):
     w = torch.randn(96, 96, 2, 2, generator=torch.Generator().manual_seed(3)) / 96 ** 0.5
     b = torch.randn(96, generator=torch.Generator().manual_seed(4))
@@ -418,6 +437,8 @@ CHECKS = {
     "conv_halo_bn192_n544": conv_halo_bn192_n544, "conv_halo_bn128_n224": conv_halo_bn128_n224, "conv_halo_bn192_n160": conv_halo_bn192_n160,
     "conv_big_gemm_scale_inplace": conv_big_gemm_scale_inplace, "conv_big_gemm_gelu_k1024": conv_big_gemm_gelu_k1024,
     "conv_big_transpose": conv_big_transpose,
+    "conv_split_n272_res_views": conv_split_n272_res_views, "conv_split_gemm_n544_inplace": conv_split_gemm_n544_inplace,
+    "conv_gemm_vitl_linear_shape": conv_gemm_vitl_linear_shape, "conv_dominant_launch": conv_dominant_launch,
     "conv_transpose": conv_transpose, "patch_embed_tokens": patch_embed_tokens, "layernorm": layernorm,
     "vit_attention": vit_attention, "swin_ops": swin_ops, "resize_ops": resize_ops, "roi_ops": roi_ops,
     "misc_ops": misc_ops, "bins_ops": bins_ops, "stitch_ops": stitch_ops,

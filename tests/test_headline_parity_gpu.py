@@ -1,0 +1,97 @@
+"""pytest -m gpu: parity AT THE CONFIGURATION THE BENCH TIMES -- BASELINE.json configs[2]: Depth-Anything ViT-L,
+2160x3840 image, 4x4 regular tiles (cai_mode m1), process_num 8 -- in both compute modes, against the oracle
+(oracle/pf_oracle.py, the restatement pinned to the reference's own Python) evaluated with torch on the same GPU.
+
+The oracle needs ~2 minutes for all 16 tiles on the GPU, so a SAMPLE of the output is checked: the whole coarse pass
+(coarse depth = every pixel of the low-resolution prediction) and the four diagonal tiles (0, 5, 10, 15) of the 4x4
+grid = 4 x 392 x 518 pixels of the final stitched map (in m1 every pixel of the map belongs to exactly one tile, so
+map == tile depth up to the 1-ulp `d*m/m` of the running average).
+
+Stated tolerances, in DEPTH UNITS (the synthetic-weight model predicts depths in [0.67, 0.79], std 0.012):
+    f32  (exact mode, the headline precision):  max |delta| <= 1e-4                        measured 1.4e-5
+    bf16 (fast mode, secondary bench figure):    max <= 5e-3, p99 <= 2e-3, mean <= 6e-4     measured 2.5e-3 / 1.1e-3 / 3.1e-4
+The bf16 budget is 2x the measured error; profiles/r2_precision_probe.json holds the per-stage growth (features carry ~1 %
+relative rms error after 24 bf16 ViT blocks, no stage amplifies; the f32 metric-bins head maps it to 5e-4 relative depth).
+The measured numbers of each run are written to gpurun_out/r2_headline_parity.json.
+"""
+import json
+import os
+
+import pytest
+import torch
+
+from oracle import pf_oracle
+from patchfusion_amd.config import make_config
+from patchfusion_amd.model import PatchFusion
+from patchfusion_amd.spec import patchfusion_spec, synthetic_state_dict
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TILES = (0, 5, 10, 15)
+TOL = {"fp32": dict(max=1e-4, p99=5e-5, mean=2e-5), "bf16": dict(max=5e-3, p99=2e-3, mean=6e-4)}
+# the coarse branch's own depth is an INTERMEDIATE (it enters the fusion net as one of 5 input channels); with the synthetic
+# weights its bin softmax is far more selective than the fusion head's (depths 0.56..0.99, std 0.039), so isolated pixels
+# near a tie between bins move by up to 0.05 in bf16 (measured max 0.053, p99 7.7e-3, mean 1.3e-3); budget = 2x measured
+TOL_COARSE = {"fp32": TOL["fp32"], "bf16": dict(max=0.11, p99=1.6e-2, mean=2.6e-3)}
+
+
+@pytest.fixture(scope="module")
+def oracle_sample():
+    cfg = make_config("vitl", (392, 518), (2160, 3840), (4, 4))
+    sd = synthetic_state_dict(patchfusion_spec(cfg), 0)
+    img = torch.rand(1, 3, 2160, 3840, generator=torch.Generator().manual_seed(1234)).cuda()
+    sdg = {k: v.cuda() for k, v in sd.items()}
+    orc = pf_oracle.Oracle(cfg, sdg)
+    with torch.no_grad():
+        lr = orc.resizer(img)
+        orc.coarse_depth, orc.coarse_feats = pf_oracle.branch_forward(sdg, "coarse_branch.", lr, cfg["coarse_branch"])
+        orc.g2l = pf_oracle.g2l_all(sdg, orc.coarse_feats)
+        tile_cfg = pf_oracle.prepare_tile_cfg(orc.ps, cfg["image_raw_shape"], cfg["patch_split_num"])
+        hr, wr = tile_cfg["patch_raw_shape"]
+        crops, boxes = [], []
+        for t in TILES:
+            h, w = (t // 4) * hr, (t % 4) * wr
+            crops.append(orc.resizer(img[:, :, h:h + hr, w:w + wr])[0])
+            boxes.append([w, h, w + wr, h + hr])
+        ref_tiles = orc._predict(torch.stack(crops), torch.tensor(boxes, device="cuda").int(), tile_cfg, 2)[:, 0].clone()
+        ref_coarse = orc.coarse_depth.clone()
+    del orc, sdg
+    torch.cuda.empty_cache()
+    return cfg, sd, img, ref_coarse, ref_tiles
+
+
+def _stats(diff):
+    d = diff.flatten().float()
+    return dict(max=float(d.max()), p99=float(torch.quantile(d[::3], 0.99)), mean=float(d.mean()))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_configs2_vitl_4k_p16_matches_oracle(oracle_sample, dtype):
+    cfg, sd, img, ref_coarse, ref_tiles = oracle_sample
+    m = PatchFusion(cfg, compute_dtype=dtype).eval()
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    lr = m.resizer(img)
+    with torch.no_grad():
+        d, _ = m(mode="infer", image_lr=lr, image_hr=img, cai_mode="m1", process_num=8)
+    torch.cuda.synchronize()
+    assert tuple(d.shape) == (1, 1, 4 * 392, 4 * 518)
+    got = torch.stack([d[0, 0, (t // 4) * 392:(t // 4 + 1) * 392, (t % 4) * 518:(t % 4 + 1) * 518] for t in TILES])
+    st_tiles = _stats((got - ref_tiles).abs())
+    st_coarse = _stats((m._coarse_state["depth"] - ref_coarse).abs())
+    rec = dict(config="BASELINE configs[2]: DA-vitl 2160x3840 4x4 m1 process_num=8", dtype=dtype, tiles=list(TILES),
+               final_map_vs_oracle=st_tiles, coarse_depth_vs_oracle=st_coarse, tolerance=TOL[dtype], tolerance_coarse=TOL_COARSE[dtype],
+               ref_depth_range=[float(ref_tiles.min()), float(ref_tiles.max())], ref_depth_std=float(ref_tiles.std()))
+    try:
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        path = os.path.join(out, "r2_headline_parity.json")
+        allrec = json.load(open(path)) if os.path.exists(path) else {}
+        allrec[dtype] = rec
+        json.dump(allrec, open(path, "w"), indent=1)
+    except OSError:
+        pass
+    for name, st, tol in (("final map", st_tiles, TOL[dtype]), ("coarse depth", st_coarse, TOL_COARSE[dtype])):
+        assert st["max"] <= tol["max"] and st["p99"] <= tol["p99"] and st["mean"] <= tol["mean"], (dtype, name, st, tol)
+    del m
+    torch.cuda.empty_cache()

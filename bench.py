@@ -64,11 +64,12 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary bf16 leg")
     ap.add_argument("--roofline-only", action="store_true", help="only time the dominant kernel (kernel tuning aid)")
     ap.add_argument("--gemm-sweep", action="store_true", help="time the ViT-L linear layers / other shapes (kernel tuning aid)")
+    ap.add_argument("--only", default="", help="gemm-sweep: comma separated shape names to run")
     args = ap.parse_args()
 
     if args.gemm_sweep:
         torch.cuda.set_device(0)
-        gemm_sweep(args.dtype, torch.device("cuda", 0))
+        gemm_sweep(args.dtype, torch.device("cuda", 0), [v for v in args.only.split(",") if v])
         return
     if args.roofline_only:
         torch.cuda.set_device(0)
@@ -178,7 +179,7 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def gemm_sweep(dtype, dev):
+def gemm_sweep(dtype, dev, only=()):
     from patchfusion_amd import packing as pk
     from patchfusion_amd.hip_ops import ops
     tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
@@ -190,6 +191,8 @@ def gemm_sweep(dtype, dev):
               ("c512_256_L2", 8 * 56 * 74, 512, 256, 3), ("c512_256_L1", 8 * 28 * 37, 512, 256, 3), ("c512_256_L0", 8 * 14 * 19, 512, 256, 3),
               ("rcu256_L3", 8 * 112 * 148, 256, 256, 3)]
     for name, M, K, N, k in shapes:
+        if only and name not in only:
+            continue
         if k == 1:
             x = torch.randn(1, 1, M, K, device=dev).to(tdt)
             y = torch.empty(1, 1, M, N, device=dev, dtype=tdt)

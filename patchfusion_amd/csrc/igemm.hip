@@ -92,6 +92,9 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 // at once form a roughly square patch of the output (8 pixel tiles x 8 channel tiles) whose A and W panels fit that
 // XCD's 4 MiB L2 together, instead of 2 pixel tiles x every channel tile (the whole weight matrix streaming through L2
 // once per pair of pixel tiles).
+#ifndef PF_F32_PIPE_DEFAULT
+#define PF_F32_PIPE_DEFAULT 0
+#endif
 #ifndef PF_IGEMM_GROUP_M
 #define PF_IGEMM_GROUP_M 8
 #endif
@@ -110,14 +113,20 @@ __device__ __forceinline__ void tile_of(int bid, int mt, int nt, int& tile_m, in
   tile_m = first_m + (in_g - tile_n * gsz);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool RELU_IN>
+// PIPE selects the K-loop pipeline: 0 = two LDS stages, chunk k+1 fetched while chunk k is multiplied (hipcc sinks half of
+// the MFMAs below the barrier, i.e. the fetch has HALF a chunk of MFMA time to land); 1 = same ring, but every MFMA of the
+// chunk is issued before the wait (a whole chunk to land); 2 = THREE stages, chunk k+2 fetched while chunk k is multiplied,
+// counted s_waitcnt vmcnt(NDMA) (two chunks to land; the f32 layers stream 9 x 3.5 GB of activations from HBM per launch).
+template <typename T, int BM, int BN, int WM, int WN, bool RELU_IN, int PIPE = 0>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p) {
   constexpr int VEC = Elem<T>::VEC;
+  constexpr int NST = PIPE == 2 ? 3 : 2;
   constexpr int BK = 8 * VEC;  // elements per 128-byte chunk row
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int FM = WTM / 16, FN = WTN / 16;
   constexpr int A_ITERS = (BM + 31) / 32, B_ITERS = (BN + 31) / 32;
   constexpr int A_BYTES = BM * 128, B_BYTES = ((BN + 31) / 32) * 32 * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int NDMA = A_ITERS + B_ITERS;          // LDS-DMA instructions per wave per chunk (the counted-vmcnt immediate)
   static_assert(WM * WN == 4, "4 waves");
   static_assert(WTM % 16 == 0 && WTN % 16 == 0 && BM % 32 == 0, "fragment multiple");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -182,7 +191,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
   const unsigned smem_base = lds_addr(smem);
   // GEMM fast path (1x1, K a multiple of the chunk): every source pointer just advances by 128 bytes per chunk
   // (0 for the zero page) - no tap/mask/select arithmetic in the K loop
-  const bool fast = ntaps == 1 && (p.Cin % BK) == 0;
+  // (PIPE 3 hides the tap / mask arithmetic of the general path in MFMA shadows: one path, half the pointer registers)
+  const bool fast = PIPE != 3 && ntaps == 1 && (p.Cin % BK) == 0;
   const char* a_cur[A_ITERS];
   int a_inc[A_ITERS];
 #pragma unroll
@@ -235,6 +245,47 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
     }
   };
 
+  // PIPE == 3: the same chunk fetch, cut into its NDMA single-instruction pieces so that they can be placed BETWEEN the
+  // MFMA groups of the chunk being multiplied (piece g goes behind MFMA group g): a wave's matrix stream then has no
+  // DMA-issue gap.  Two co-resident waves of different blocks run the same code at the same pace and fall into
+  // lock-step, so a gap in one wave's stream is a gap in both -- the matrix pipe idles (PMC of PIPE 0: 17 % idle with
+  // s_waitcnt / barrier time of only 7 %; three LDS stages or more blocks per CU did not help, profiles/r2_f32_tune.json).
+  long koff_cur = 0;
+  auto issue_begin = [&]() {
+    if (!fast) koff_cur = ((long)(ky * p.W + kx) * p.x_ld + cv * VEC) * (long)sizeof(T);
+  };
+  auto issue_piece = [&](int stage, int kc, int g) {     // g is a compile-time constant after unrolling
+    const unsigned As = smem_base + stage * STAGE + wave * (8 * 128);
+    const unsigned Bs = As + A_BYTES;
+    if (g < A_ITERS) {
+      const int i = g;
+      if (fast) {
+        glds16(a_cur[i], As + i * (32 * 128));
+        a_cur[i] += a_inc[i];
+      } else {
+        const bool ok = (a_mask[i] >> tap) & 1u;
+        glds16(ok ? a_ptr[i] + koff_cur : zero, As + i * (32 * 128));
+      }
+    } else if (g < NDMA) {
+      const int i = g - A_ITERS;
+      if (fast) {
+        glds16(b_cur[i], Bs + i * (32 * 128));
+        b_cur[i] += b_inc[i];
+      } else {
+        glds16(b_ptr[i] ? b_ptr[i] + (long)kc * (BK * (long)sizeof(T)) : zero, Bs + i * (32 * 128));
+      }
+    }
+  };
+  auto issue_end = [&]() {
+    if (fast) return;
+    cv += 8;
+    while (cv >= cin_v) {
+      cv -= cin_v;
+      ++tap;
+      if (++kx == p.KW) { kx = 0; ++ky; }
+    }
+  };
+
   f32x4 acc[FN][FM];
 #pragma unroll
   for (int fn = 0; fn < FN; ++fn)
@@ -251,7 +302,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
     const int n = n0 + wn * WTN + fn * 16 + fg * 4;
     bias_r[fn] = make_float4(0.f, 0.f, 0.f, 0.f);
     scale_r[fn] = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (p.shuffle <= 1 && n < p.Cout) {
+    if (PIPE != 3 && p.shuffle <= 1 && n < p.Cout) {
       if (p.bias) bias_r[fn] = *reinterpret_cast<const float4*>(p.bias + n);
       if (p.scale) scale_r[fn] = *reinterpret_cast<const float4*>(p.scale + n);
     }
@@ -263,14 +314,63 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
 #ifndef PF_ABL_NOPRO
   issue(0, 0);
 #endif
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (PIPE == 2) {
+    if (nk > 1) {
+      issue(1, 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");   // chunk 0 landed, chunk 1 stays in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __syncthreads();
+  int st = 0;                                         // ring stage of chunk kc
   for (int kc = 0; kc < nk; ++kc) {
 #ifndef PF_ABL_NODMA
-    if (kc + 1 < nk) issue((kc + 1) & 1, kc + 1);   // next chunk lands while this one is multiplied
+    if constexpr (PIPE == 2) {
+      if (kc + 2 < nk) issue(st == 0 ? 2 : st - 1, kc + 2);   // (st + 2) % 3: the stage consumed in iteration kc-1
+    } else if constexpr (PIPE != 3) {
+      if (kc + 1 < nk) issue(st ^ 1, kc + 1);        // next chunk lands while this one is multiplied
+    }
 #endif
-    const char* As = smem + (kc & 1) * STAGE;
+    const char* As = smem + st * STAGE;
     const char* Bs = As + A_BYTES;
+    if constexpr (PIPE == 3 && sizeof(T) == 4) {
+      static_assert(NDMA <= 8, "one DMA piece per MFMA group");
+      // all 2 x (FM + FN) fragment reads of the chunk first, then 8 MFMA groups (half s, k element e) with DMA piece g of
+      // chunk kc+1 behind group g
+      uint4 wf[2][FN], xf[2][FM];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int slot = (((s << 2) | fg) ^ swz) << 4;
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) wf[s][fn] = *reinterpret_cast<const uint4*>(Bs + b_row_off + fn * 16 * 128 + slot);
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+          xf[s][fm] = *reinterpret_cast<const uint4*>(As + a_row_off + fm * 16 * 128 + slot);
+          if constexpr (RELU_IN) xf[s][fm] = relu_vec<T>(xf[s][fm]);
+        }
+      }
+      const bool more = kc + 1 < nk;
+      if (more) issue_begin();
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const int s = g >> 2, e = g & 3;
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+          for (int fm = 0; fm < FM; ++fm) {
+            const uint32_t a = e == 0 ? wf[s][fn].x : e == 1 ? wf[s][fn].y : e == 2 ? wf[s][fn].z : wf[s][fn].w;
+            const uint32_t b = e == 0 ? xf[s][fm].x : e == 1 ? xf[s][fm].y : e == 2 ? xf[s][fm].z : xf[s][fm].w;
+            acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a), __uint_as_float(b), acc[fn][fm], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) issue_piece(st ^ 1, kc + 1, g);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (more) issue_end();
+    } else {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int slot = (((s << 2) | fg) ^ swz) << 4;
@@ -285,11 +385,31 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
       if constexpr (sizeof(T) == 2) mma_half_bf16<FM, FN>(wf, xf, acc);
       else mma_half_f32<FM, FN>(wf, xf, acc);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk kc+1 has landed (this wave's pieces) ...
-    __syncthreads();                                    // ... for every wave; and stage kc&1 is free again
+    }
+    if constexpr (PIPE == 1 || PIPE == 2) __builtin_amdgcn_sched_barrier(0);   // every MFMA of this chunk is issued before the wait
+    if constexpr (PIPE == 2) {
+      if (kc + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");   // chunk kc+1 landed, kc+2 in flight
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      st = st == 2 ? 0 : st + 1;
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk kc+1 has landed (this wave's pieces) ...
+      __syncthreads();                                    // ... for every wave; and stage kc&1 is free again
+      st ^= 1;
+    }
   }
 
   // ---- epilogue: bias -> act -> scale -> residual(s) -> store 4 consecutive channels ----
+  if constexpr (PIPE == 3) {     // (not preloaded: 2 x FN float4 registers would cost the second wave per SIMD)
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) {
+      const int n = n0 + wn * WTN + fn * 16 + fg * 4;
+      if (p.shuffle <= 1 && n < p.Cout) {
+        if (p.bias) bias_r[fn] = *reinterpret_cast<const float4*>(p.bias + n);
+        if (p.scale) scale_r[fn] = *reinterpret_cast<const float4*>(p.scale + n);
+      }
+    }
+  }
   const int s = p.shuffle > 1 ? p.shuffle : 1;
   const int cout_t = p.Cout / (s * s);
 #pragma unroll
@@ -1249,11 +1369,11 @@ int launch_halo(const pf_conv_params& p, hipStream_t st) {
 
 thread_local char g_err[256] = {0};
 
-template <typename T, int BM, int BN, int WM, int WN, bool RELU_IN>
+template <typename T, int BM, int BN, int WM, int WN, bool RELU_IN, int PIPE>
 int launch_cfg2(const pf_conv_params& p, hipStream_t st) {
-  constexpr int smem = 2 * (BM + ((BN + 31) / 32) * 32) * 128;
+  constexpr int smem = (PIPE == 2 ? 3 : 2) * (BM + ((BN + 31) / 32) * 32) * 128;
   static std::atomic<unsigned long long> attr_done{0};
-  auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, RELU_IN>;
+  auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, RELU_IN, PIPE>;
   ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
   const long M = (long)p.B * p.OH * p.OW;
   const long mt = (M + BM - 1) / BM, nt = (p.Cout + BN - 1) / BN;
@@ -1261,9 +1381,20 @@ int launch_cfg2(const pf_conv_params& p, hipStream_t st) {
   return launch_status();
 }
 
+int f32_pipe() {     // PF_F32_PIPE (read per call): K-loop pipeline of the f32 generic kernel, see conv_igemm_kernel
+  const char* e = getenv("PF_F32_PIPE");
+  return e ? atoi(e) : PF_F32_PIPE_DEFAULT;
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_cfg(const pf_conv_params& p, hipStream_t st) {
-  return p.relu_in ? launch_cfg2<T, BM, BN, WM, WN, true>(p, st) : launch_cfg2<T, BM, BN, WM, WN, false>(p, st);
+  if constexpr (sizeof(T) == 4 && BM * BN <= 128 * 128 && BN >= 64) {
+    const int pipe = f32_pipe();
+    if (pipe == 3) return p.relu_in ? launch_cfg2<T, BM, BN, WM, WN, true, 3>(p, st) : launch_cfg2<T, BM, BN, WM, WN, false, 3>(p, st);
+    if (pipe == 2) return p.relu_in ? launch_cfg2<T, BM, BN, WM, WN, true, 2>(p, st) : launch_cfg2<T, BM, BN, WM, WN, false, 2>(p, st);
+    if (pipe == 1) return p.relu_in ? launch_cfg2<T, BM, BN, WM, WN, true, 1>(p, st) : launch_cfg2<T, BM, BN, WM, WN, false, 1>(p, st);
+  }
+  return p.relu_in ? launch_cfg2<T, BM, BN, WM, WN, true, 0>(p, st) : launch_cfg2<T, BM, BN, WM, WN, false, 0>(p, st);
 }
 
 int g_force_small = -1;   // PF_IGEMM_SMALL=1 forces the 4-wave kernel everywhere (A/B measurements)
@@ -1392,13 +1523,11 @@ int launch_generic(const pf_conv_params& p, hipStream_t st, int cfg) {
 template <typename T>
 int dispatch_generic(const pf_conv_params& p, hipStream_t st, bool allow_split) {
   const long M = (long)p.B * p.OH * p.OW;
-  static int force_cfg = -2, no_split = -1;
-  if (force_cfg == -2) {
-    const char* e = getenv("PF_IGEMM_CFG");
-    force_cfg = e ? atoi(e) : -1;
-    const char* e2 = getenv("PF_IGEMM_NOSPLIT");
-    no_split = e2 ? atoi(e2) : 0;
-  }
+  // PF_IGEMM_CFG / PF_IGEMM_NOSPLIT are kernel-tuning overrides, read per call (a getenv is ~50 ns against a >= 2 us launch)
+  const char* e = getenv("PF_IGEMM_CFG");
+  const int force_cfg = e ? atoi(e) : -1;
+  const char* e2 = getenv("PF_IGEMM_NOSPLIT");
+  const int no_split = e2 ? atoi(e2) : 0;
   double cost_single;
   int best = best_cfg<T>(p, M, p.Cout, &cost_single);
   if (force_cfg >= 0 && !(force_cfg == 0 && sizeof(T) != 2) && !(force_cfg == 6 && sizeof(T) != 4)) return launch_generic<T>(p, st, force_cfg);

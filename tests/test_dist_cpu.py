@@ -62,6 +62,18 @@ def _worker_shard(rank, world, port, mode, shard, out_dir):
     dist.destroy_process_group()
 
 
+def _worker_shard_8x8(rank, world, port, out_dir):
+    """BASELINE configs[3] in miniature: an 8x8 grid (64 tiles) of ONE image sharded over the ranks, 32 tiles per rank."""
+    _init(rank, world, port)
+    m = _model("kwarg")
+    img = torch.rand(1, 3, 448, 640, generator=torch.Generator().manual_seed(77))
+    tc = {"image_raw_shape": (448, 640), "patch_split_num": (8, 8)}
+    with torch.no_grad():
+        d, _ = m(mode="infer", image_lr=m.resizer(img), image_hr=img, tile_cfg=tc, cai_mode="m1", process_num=8)
+    np.save(os.path.join(out_dir, f"rank{rank}.npy"), d.numpy())
+    dist.destroy_process_group()
+
+
 def _worker_image_dp(rank, world, port, n_images, out_dir):
     """the reference's own multi-GPU evaluation (tools/test.py:218-239, tester.py:46-64): DDP + DistributedSampler,
     every rank a DIFFERENT image, default-constructed model -> no tile sharding, no collective, correct maps.  With an odd
@@ -113,6 +125,19 @@ def test_two_rank_patch_sharding_matches_golden(tmp_path, golden_dir, mode, shar
     assert np.array_equal(a, b)                                   # every rank stitches the same map
     ref = np.load(os.path.join(golden_dir, "tiny_vits.npz"))[f"depth_{mode}"]   # r4 golden: random.seed(5621) = rank 0's state
     assert a[0, 0].shape == ref.shape and np.abs(a[0, 0] - ref).max() < 2e-5
+
+
+def test_8x8_grid_sharded_two_ways_equals_single_process(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker_shard_8x8, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "rank0.npy"), np.load(tmp_path / "rank1.npy")
+    assert np.array_equal(a, b) and a.shape == (1, 1, 8 * 112, 8 * 154)
+    single = _model(None)
+    img = torch.rand(1, 3, 448, 640, generator=torch.Generator().manual_seed(77))
+    with torch.no_grad():
+        ref, _ = single(mode="infer", image_lr=single.resizer(img), image_hr=img,
+                        tile_cfg={"image_raw_shape": (448, 640), "patch_split_num": (8, 8)}, cai_mode="m1", process_num=8)
+    assert np.abs(a - ref.numpy()).max() < 2e-5
 
 
 @pytest.mark.parametrize("n_images", [2, 3])

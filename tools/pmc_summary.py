@@ -1,0 +1,71 @@
+"""Summarise rocprofv3 --pmc passes of ONE kernel (the dominant launch of `bench.py --roofline-only`) into a JSON for profiles/.
+
+usage: python tools/pmc_summary.py <dtype> <kernel-substring> <out.json> <pass_dir> [<pass_dir> ...]
+Every pass dir holds *_counter_collection.csv of one `rocprofv3 --pmc ... --kernel-trace --output-format csv` run.
+Counters are averaged over the dispatches of the matching kernel with the LARGEST grid (the roofline launch).
+Units (MI355X_MICROARCH.md): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves;
+SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs;
+FETCH_SIZE (KB) reports 1/2 of a wide coalesced read stream on gfx950 -> doubled; WRITE_SIZE (KB) as is.
+"""
+import csv
+import glob
+import hashlib
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    dtype, sub, out = sys.argv[1], sys.argv[2], sys.argv[3]
+    vals, durs, grid = defaultdict(list), [], 0
+    rows = []
+    for d in sys.argv[4:]:
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            with open(f) as fh:
+                rows += [r for r in csv.DictReader(fh) if sub in r["Kernel_Name"]]
+    if not rows:
+        print("no rows for", sub)
+        return
+    grid = max(int(r["Grid_Size"]) for r in rows)
+    name = ""
+    for r in rows:
+        if int(r["Grid_Size"]) != grid:
+            continue
+        name = r["Kernel_Name"]
+        vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        durs.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    per = {k: sum(v) / len(v) for k, v in vals.items()}
+    ms = sum(durs) / len(durs)
+    der = {"ms_per_launch_profiled": ms}
+    if "GRBM_GUI_ACTIVE" in per:
+        cyc = per["GRBM_GUI_ACTIVE"] / 8.0
+        der["kernel_cycles_per_xcd"] = cyc
+        der["effective_clock_GHz"] = cyc / (ms * 1e-3) / 1e9
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in per:
+            der["mfma_pipe_busy_frac"] = per["SQ_VALU_MFMA_BUSY_CYCLES"] / (256 * 4) / cyc
+    if "SQ_WAVE_CYCLES" in per:
+        for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS",
+                  "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_MISC", "SQ_ACTIVE_INST_SCA"):
+            if k in per:
+                der[k + "_frac_of_wave_cycles"] = per[k] / per["SQ_WAVE_CYCLES"]
+    if "FETCH_SIZE" in per:
+        der["hbm_read_bytes_corrected_x2"] = per["FETCH_SIZE"] * 1024 * 2
+    if "WRITE_SIZE" in per:
+        der["hbm_write_bytes"] = per["WRITE_SIZE"] * 1024
+    if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
+        der["traffic_bytes"] = der["hbm_read_bytes_corrected_x2"] + der["hbm_write_bytes"]
+    h = hashlib.sha256()
+    for f in ("igemm.hip", "pf_common.h"):
+        h.update(open(os.path.join(ROOT, "patchfusion_amd", "csrc", f), "rb").read())
+    j = {"kernel": name, "grid": grid, "dtype": dtype, "kernel_source_sha": h.hexdigest()[:12], "dispatches_averaged": len(durs),
+         "command": "rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python bench.py --roofline-only --dtype " + dtype,
+         "per_launch": per, "derived": der}
+    json.dump(j, open(out, "w"), indent=1)
+    print(json.dumps(der, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -244,6 +244,25 @@ def branch_forward(sd, p, x, bcfg, taps=None):
     return depth, [x_d0] + x_blocks + [hk["out_conv"]]
 
 
+def branch_forward_external(sd, p, x, bcfg, provider, taps=None):
+    """ZoeDepth.forward for a MiDaS-core branch (type 'ZoeDepth', BASELINE configs[4]) with the relative-depth core supplied
+    from OUTSIDE -- the reference's own injection point `hack_feature=(rel_depth, out)`, zoedepth_v1.py:160-166:
+    provider(x) -> (rel_depth [B,H,W], [btlnck, x_block0..3, outconv_activation]).  PARITY UNPINNED for the core itself: it is
+    the un-vendored torch.hub repo AyaanShah2204/MiDaS (midas.py:340); everything after it (conv2, the metric-bins head) is
+    the same arithmetic as the Depth-Anything branch: zoedepth_v1.py:170-219."""
+    rel, out = provider(x)
+    btl, x_blocks, last = out[0], list(out[1:5]), out[5]
+    x_d0 = conv(sd, p + "conv2", btl)
+    depth = bins_head(sd, p, x_d0, x_blocks, last, rel.unsqueeze(1), bcfg, taps)
+    return depth, [x_d0] + x_blocks + [last]
+
+
+def any_branch_forward(sd, p, x, bcfg, provider=None, taps=None):
+    if bcfg["type"] == "ZoeDepth":
+        return branch_forward_external(sd, p, x, bcfg, provider, taps)
+    return branch_forward(sd, p, x, bcfg, taps)
+
+
 # ------------------------------------------------------------------------------------------
 # G2L (Swin) + guided fusion
 # ------------------------------------------------------------------------------------------
@@ -424,8 +443,10 @@ class RunningAverageMap:
 class Oracle:
     """Stateful wrapper reproducing PatchFusion.forward(mode='infer') -- patchfusion.py:401-453."""
 
-    def __init__(self, cfg, sd, hoist_g2l=True):
+    def __init__(self, cfg, sd, hoist_g2l=True, core_providers=None):
+        """core_providers = (coarse, fine) feature providers, only for type 'ZoeDepth' branches (branch_forward_external)"""
         self.cfg, self.sd = cfg, sd
+        self.providers = core_providers or (None, None)
         self.ps = tuple(cfg["patch_process_shape"])
         self.hoist_g2l = hoist_g2l      # exact algebraic saving; False follows the reference schedule
         self.taps = None
@@ -450,7 +471,7 @@ class Oracle:
         preds = []
         for s in range(0, crops.shape[0], process_num):
             sl = slice(s, s + process_num)
-            fine_depth, fine_feats = branch_forward(self.sd, "fine_branch.", crops[sl], self.cfg["fine_branch"])
+            fine_depth, fine_feats = any_branch_forward(self.sd, "fine_branch.", crops[sl], self.cfg["fine_branch"], self.providers[1])
             bb = bf[sl].clone()
             bb[:, 0] = 0
             preds.append(fusion_forward(self.sd, self.cfg, fine_depth, crops[sl], self.coarse_feats, fine_feats, bb,
@@ -527,7 +548,8 @@ class Oracle:
             tile_cfg = dict(image_raw_shape=cfg["image_raw_shape"], patch_split_num=cfg["patch_split_num"])
         tile_cfg = prepare_tile_cfg(self.ps, tile_cfg["image_raw_shape"], tile_cfg["patch_split_num"])
         assert image_hr.shape[0] == 1
-        self.coarse_depth, self.coarse_feats = branch_forward(self.sd, "coarse_branch.", image_lr, cfg["coarse_branch"], taps)
+        self.coarse_depth, self.coarse_feats = any_branch_forward(self.sd, "coarse_branch.", image_lr, cfg["coarse_branch"],
+                                                                  self.providers[0], taps)
         if taps is not None:
             taps["coarse_depth"] = self.coarse_depth
             for i, f in enumerate(self.coarse_feats):

@@ -55,11 +55,14 @@ class AttrDict(dict):
             f.write(self.to_json_string())
 
 
-def pyramid_sizes(process_shape):
-    """(h, w) of the six feature levels L5..L0 for a Depth-Anything branch at ``process_shape``
-    (external/depth_anything/dpt.py:41-63,97-130): full res, 8x/4x/2x/1x the token grid and the
-    stride-2 conv of the token grid."""
+def pyramid_sizes(process_shape, branch_type="DA-ZoeDepth"):
+    """(h, w) of the six feature levels L5..L0 at ``process_shape``.
+    Depth-Anything branch (external/depth_anything/dpt.py:41-63,97-130): full res, 8x/4x/2x/1x the token grid and the
+    stride-2 conv of the token grid.  MiDaS-core ZoeDepth branch (guided_fusion_model.py:112 defaults, 384x512 ->
+    384x512, 192x256, 96x128, 48x64, 24x32, 12x16): full res and the /2 ... /32 levels of the DPT decoder."""
     h, w = process_shape
+    if branch_type == "ZoeDepth":
+        return [(h, w)] + [(h // s, w // s) for s in (2, 4, 8, 16, 32)]
     th, tw = h // VIT_PATCH, w // VIT_PATCH
     return [(h, w), (th * 8, tw * 8), (th * 4, tw * 4), (th * 2, tw * 2), (th, tw), ((th + 1) // 2, (tw + 1) // 2)]
 
@@ -73,6 +76,33 @@ def zoe_branch_config(encoder, process_shape, min_depth=1e-3, max_depth=80):
         bin_centers_type="softplus", bin_embedding_dim=128, inverse_midas=False, max_temp=50.0,
         min_temp=0.0212, memory_efficient=True, n_attractors=[16, 8, 4, 1], n_bins=64,
         output_distribution="logbinomial", force_keep_ar=True)
+
+
+def zoe_midas_branch_config(process_shape=(384, 512), min_depth=1e-3, max_depth=80):
+    """the branch section of configs/patchfusion_zoedepth/zoedepth_patchfusion_u4k.py:10-50 (MiDaS DPT_BEiT_L_384 core)"""
+    c = zoe_branch_config("vitl", process_shape, min_depth, max_depth)
+    c.update(type="ZoeDepth", midas_model_type="DPT_BEiT_L_384", pretrained_resource=None)
+    c.pop("depth_anything")
+    return c
+
+
+def make_zoe_config(process_shape=(384, 512), image_raw_shape=(2160, 3840), patch_split_num=(4, 4), min_depth=1e-3, max_depth=80,
+                    explicit_fusion_geometry=None):
+    """``model.config`` of configs/patchfusion_zoedepth/zoedepth_patchfusion_u4k.py:55-72 (BASELINE configs[4]).  The shipped
+    file relies on GuidedFusionPatchFusion's 384x512 defaults; for other (test) process shapes -- multiples of 32 -- the
+    geometry is spelled out like the Depth-Anything configs do."""
+    gf = dict(type="GuidedFusionPatchFusion", n_channels=5, g2l=True)
+    if explicit_fusion_geometry or tuple(process_shape) != (384, 512):
+        sizes = pyramid_sizes(process_shape, "ZoeDepth")
+        gf.update(patch_process_shape=tuple(process_shape), in_channels=[32, 256, 256, 256, 256, 256],
+                  num_patches=[a * b for a, b in sizes])
+    return dict(
+        image_raw_shape=tuple(image_raw_shape), patch_split_num=tuple(patch_split_num),
+        patch_process_shape=tuple(process_shape), min_depth=min_depth, max_depth=max_depth,
+        load_branch=False, pretrain_model=["", ""],
+        coarse_branch=zoe_midas_branch_config(process_shape, min_depth, max_depth),
+        fine_branch=zoe_midas_branch_config(process_shape, min_depth, max_depth),
+        guided_fusion=gf, sigloss=dict(type="SILogLoss"))
 
 
 def make_config(encoder="vitl", process_shape=(392, 518), image_raw_shape=(2160, 3840),

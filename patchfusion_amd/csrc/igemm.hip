@@ -92,9 +92,6 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 // at once form a roughly square patch of the output (8 pixel tiles x 8 channel tiles) whose A and W panels fit that
 // XCD's 4 MiB L2 together, instead of 2 pixel tiles x every channel tile (the whole weight matrix streaming through L2
 // once per pair of pixel tiles).
-#ifndef PF_F32_PIPE_DEFAULT
-#define PF_F32_PIPE_DEFAULT 0
-#endif
 #ifndef PF_IGEMM_GROUP_M
 #define PF_IGEMM_GROUP_M 8
 #endif
@@ -113,20 +110,14 @@ __device__ __forceinline__ void tile_of(int bid, int mt, int nt, int& tile_m, in
   tile_m = first_m + (in_g - tile_n * gsz);
 }
 
-// PIPE selects the K-loop pipeline: 0 = two LDS stages, chunk k+1 fetched while chunk k is multiplied (hipcc sinks half of
-// the MFMAs below the barrier, i.e. the fetch has HALF a chunk of MFMA time to land); 1 = same ring, but every MFMA of the
-// chunk is issued before the wait (a whole chunk to land); 2 = THREE stages, chunk k+2 fetched while chunk k is multiplied,
-// counted s_waitcnt vmcnt(NDMA) (two chunks to land; the f32 layers stream 9 x 3.5 GB of activations from HBM per launch).
-template <typename T, int BM, int BN, int WM, int WN, bool RELU_IN, int PIPE = 0>
+template <typename T, int BM, int BN, int WM, int WN, bool RELU_IN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p) {
   constexpr int VEC = Elem<T>::VEC;
-  constexpr int NST = PIPE == 2 ? 3 : 2;
   constexpr int BK = 8 * VEC;  // elements per 128-byte chunk row
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int FM = WTM / 16, FN = WTN / 16;
   constexpr int A_ITERS = (BM + 31) / 32, B_ITERS = (BN + 31) / 32;
   constexpr int A_BYTES = BM * 128, B_BYTES = ((BN + 31) / 32) * 32 * 128, STAGE = A_BYTES + B_BYTES;
-  constexpr int NDMA = A_ITERS + B_ITERS;          // LDS-DMA instructions per wave per chunk (the counted-vmcnt immediate)
   static_assert(WM * WN == 4, "4 waves");
   static_assert(WTM % 16 == 0 && WTN % 16 == 0 && BM % 32 == 0, "fragment multiple");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -191,8 +182,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
   const unsigned smem_base = lds_addr(smem);
   // GEMM fast path (1x1, K a multiple of the chunk): every source pointer just advances by 128 bytes per chunk
   // (0 for the zero page) - no tap/mask/select arithmetic in the K loop
-  // (PIPE 3 hides the tap / mask arithmetic of the general path in MFMA shadows: one path, half the pointer registers)
-  const bool fast = PIPE != 3 && ntaps == 1 && (p.Cin % BK) == 0;
+  const bool fast = ntaps == 1 && (p.Cin % BK) == 0;
   const char* a_cur[A_ITERS];
   int a_inc[A_ITERS];
 #pragma unroll
@@ -245,47 +235,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
     }
   };
 
-  // PIPE == 3: the same chunk fetch, cut into its NDMA single-instruction pieces so that they can be placed BETWEEN the
-  // MFMA groups of the chunk being multiplied (piece g goes behind MFMA group g): a wave's matrix stream then has no
-  // DMA-issue gap.  Two co-resident waves of different blocks run the same code at the same pace and fall into
-  // lock-step, so a gap in one wave's stream is a gap in both -- the matrix pipe idles (PMC of PIPE 0: 17 % idle with
-  // s_waitcnt / barrier time of only 7 %; three LDS stages or more blocks per CU did not help, profiles/r2_f32_tune.json).
-  long koff_cur = 0;
-  auto issue_begin = [&]() {
-    if (!fast) koff_cur = ((long)(ky * p.W + kx) * p.x_ld + cv * VEC) * (long)sizeof(T);
-  };
-  auto issue_piece = [&](int stage, int kc, int g) {     // g is a compile-time constant after unrolling
-    const unsigned As = smem_base + stage * STAGE + wave * (8 * 128);
-    const unsigned Bs = As + A_BYTES;
-    if (g < A_ITERS) {
-      const int i = g;
-      if (fast) {
-        glds16(a_cur[i], As + i * (32 * 128));
-        a_cur[i] += a_inc[i];
-      } else {
-        const bool ok = (a_mask[i] >> tap) & 1u;
-        glds16(ok ? a_ptr[i] + koff_cur : zero, As + i * (32 * 128));
-      }
-    } else if (g < NDMA) {
-      const int i = g - A_ITERS;
-      if (fast) {
-        glds16(b_cur[i], Bs + i * (32 * 128));
-        b_cur[i] += b_inc[i];
-      } else {
-        glds16(b_ptr[i] ? b_ptr[i] + (long)kc * (BK * (long)sizeof(T)) : zero, Bs + i * (32 * 128));
-      }
-    }
-  };
-  auto issue_end = [&]() {
-    if (fast) return;
-    cv += 8;
-    while (cv >= cin_v) {
-      cv -= cin_v;
-      ++tap;
-      if (++kx == p.KW) { kx = 0; ++ky; }
-    }
-  };
-
   f32x4 acc[FN][FM];
 #pragma unroll
   for (int fn = 0; fn < FN; ++fn)
@@ -302,7 +251,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
     const int n = n0 + wn * WTN + fn * 16 + fg * 4;
     bias_r[fn] = make_float4(0.f, 0.f, 0.f, 0.f);
     scale_r[fn] = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (PIPE != 3 && p.shuffle <= 1 && n < p.Cout) {
+    if (p.shuffle <= 1 && n < p.Cout) {
       if (p.bias) bias_r[fn] = *reinterpret_cast<const float4*>(p.bias + n);
       if (p.scale) scale_r[fn] = *reinterpret_cast<const float4*>(p.scale + n);
     }
@@ -314,67 +263,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
 #ifndef PF_ABL_NOPRO
   issue(0, 0);
 #endif
-  if constexpr (PIPE == 2) {
-    if (nk > 1) {
-      issue(1, 1);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");   // chunk 0 landed, chunk 1 stays in flight
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  int st = 0;                                         // ring stage of chunk kc
   for (int kc = 0; kc < nk; ++kc) {
 #ifndef PF_ABL_NODMA
-    if constexpr (PIPE == 2) {
-      if (kc + 2 < nk) issue(st == 0 ? 2 : st - 1, kc + 2);   // (st + 2) % 3: the stage consumed in iteration kc-1
-    } else if constexpr (PIPE != 3) {
-      if (kc + 1 < nk) issue(st ^ 1, kc + 1);        // next chunk lands while this one is multiplied
-    }
+    if (kc + 1 < nk) issue((kc + 1) & 1, kc + 1);   // next chunk lands while this one is multiplied
 #endif
-    const char* As = smem + st * STAGE;
+    const char* As = smem + (kc & 1) * STAGE;
     const char* Bs = As + A_BYTES;
-    if constexpr (PIPE == 3 && sizeof(T) == 4) {
-      static_assert(NDMA <= 8, "one DMA piece per MFMA group");
-      // all 2 x (FM + FN) fragment reads of the chunk first, then 8 MFMA groups (half s, k element e) with DMA piece g of
-      // chunk kc+1 behind group g
-      uint4 wf[2][FN], xf[2][FM];
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int slot = (((s << 2) | fg) ^ swz) << 4;
-#pragma unroll
-        for (int fn = 0; fn < FN; ++fn) wf[s][fn] = *reinterpret_cast<const uint4*>(Bs + b_row_off + fn * 16 * 128 + slot);
-#pragma unroll
-        for (int fm = 0; fm < FM; ++fm) {
-          xf[s][fm] = *reinterpret_cast<const uint4*>(As + a_row_off + fm * 16 * 128 + slot);
-          if constexpr (RELU_IN) xf[s][fm] = relu_vec<T>(xf[s][fm]);
-        }
-      }
-      const bool more = kc + 1 < nk;
-      if (more) issue_begin();
-#pragma unroll
-      for (int g = 0; g < 8; ++g) {
-        const int s = g >> 2, e = g & 3;
-#pragma unroll
-        for (int fn = 0; fn < FN; ++fn)
-#pragma unroll
-          for (int fm = 0; fm < FM; ++fm) {
-            const uint32_t a = e == 0 ? wf[s][fn].x : e == 1 ? wf[s][fn].y : e == 2 ? wf[s][fn].z : wf[s][fn].w;
-            const uint32_t b = e == 0 ? xf[s][fm].x : e == 1 ? xf[s][fm].y : e == 2 ? xf[s][fm].z : xf[s][fm].w;
-            acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a), __uint_as_float(b), acc[fn][fm], 0, 0, 0);
-          }
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) issue_piece(st ^ 1, kc + 1, g);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (more) issue_end();
-    } else {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int slot = (((s << 2) | fg) ^ swz) << 4;
       uint4 wf[FN], xf[FM];
+#ifdef PF_ABL_NOLDS   // measurement build: operands from registers instead of LDS
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn) { wf[fn] = make_uint4(slot, kc, lane, fn); asm volatile("" : "+v"(wf[fn].x), "+v"(wf[fn].y), "+v"(wf[fn].z), "+v"(wf[fn].w)); }
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm) { xf[fm] = make_uint4(slot, kc, lane, fm); asm volatile("" : "+v"(xf[fm].x), "+v"(xf[fm].y), "+v"(xf[fm].z), "+v"(xf[fm].w)); }
+      (void)As; (void)Bs;
+#else
 #pragma unroll
       for (int fn = 0; fn < FN; ++fn) wf[fn] = *reinterpret_cast<const uint4*>(Bs + b_row_off + fn * 16 * 128 + slot);
 #pragma unroll
@@ -382,34 +289,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
         xf[fm] = *reinterpret_cast<const uint4*>(As + a_row_off + fm * 16 * 128 + slot);
         if constexpr (RELU_IN) xf[fm] = relu_vec<T>(xf[fm]);
       }
+#endif
       if constexpr (sizeof(T) == 2) mma_half_bf16<FM, FN>(wf, xf, acc);
       else mma_half_f32<FM, FN>(wf, xf, acc);
     }
-    }
-    if constexpr (PIPE == 1 || PIPE == 2) __builtin_amdgcn_sched_barrier(0);   // every MFMA of this chunk is issued before the wait
-    if constexpr (PIPE == 2) {
-      if (kc + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");   // chunk kc+1 landed, kc+2 in flight
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      st = st == 2 ? 0 : st + 1;
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk kc+1 has landed (this wave's pieces) ...
-      __syncthreads();                                    // ... for every wave; and stage kc&1 is free again
-      st ^= 1;
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk kc+1 has landed (this wave's pieces) ...
+#ifndef PF_ABL_NOBAR
+    __syncthreads();                                    // ... for every wave; and stage kc&1 is free again
+#endif
   }
 
   // ---- epilogue: bias -> act -> scale -> residual(s) -> store 4 consecutive channels ----
-  if constexpr (PIPE == 3) {     // (not preloaded: 2 x FN float4 registers would cost the second wave per SIMD)
-#pragma unroll
-    for (int fn = 0; fn < FN; ++fn) {
-      const int n = n0 + wn * WTN + fn * 16 + fg * 4;
-      if (p.shuffle <= 1 && n < p.Cout) {
-        if (p.bias) bias_r[fn] = *reinterpret_cast<const float4*>(p.bias + n);
-        if (p.scale) scale_r[fn] = *reinterpret_cast<const float4*>(p.scale + n);
-      }
-    }
-  }
   const int s = p.shuffle > 1 ? p.shuffle : 1;
   const int cout_t = p.Cout / (s * s);
 #pragma unroll
@@ -480,6 +370,192 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
       if (p.out_f32) store4(reinterpret_cast<float*>(p.y) + opix * p.y_ld + co, v[0], v[1], v[2], v[3]);
       else store4(reinterpret_cast<T*>(p.y) + opix * p.y_ld + co, v[0], v[1], v[2], v[3]);
 #endif
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// WAVE-SPECIALISED variant of conv_igemm_kernel: WM*WN compute waves + ONE loader wave (the last wave of the block).
+// Why (profiles/r2_abl_f32.log, f32 3x3 768->768 @ 8x224x296): the kernel above runs at 132.9 TF/s; the same kernel
+// without its in-loop LDS-DMA runs at 148.2 (94 % of the f32 MFMA peak), without barrier 134.7, without LDS reads 128.9.
+// A wave is in-order: every global_load_lds it issues costs it ~100 cycles of issue time (MI355X_MICROARCH.md "LDS-DMA
+// piece issue cost") during which it cannot feed the matrix pipe, and three-stage rings / more blocks per CU / DMA pieces
+// interleaved between MFMA groups all measured WORSE (profiles/r2_f32_tune*.log).  So the compute waves issue no VMEM at
+// all in the K loop: the loader wave owns every DMA instruction of the block (BM/8 + BN/8 pieces of 8 rows x 128 B per
+// chunk, ~32 x 100 cycles against a chunk period of 2 x 4096 MFMA cycles with two co-resident blocks), waits for them
+// (vmcnt) and meets the compute waves at the one barrier per chunk.  Same LDS image, same source-side swizzle, same
+// K order per output element -> results are bit-identical to conv_igemm_kernel.
+// Requirements (dispatcher): Cin % BK == 0 (a chunk never straddles two filter taps, so tap / ky / kx are wave-uniform),
+// shuffle <= 1.
+// -------------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int WM, int WN, bool RELU_IN>
+__global__ __launch_bounds__(64 * (WM * WN + 1), 3) void conv_igemm_ws_kernel(const pf_conv_params p) {
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int BK = 8 * VEC;
+  constexpr int NW = WM * WN;                           // compute waves
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int FM = WTM / 16, FN = WTN / 16;
+  constexpr int AP = BM / 8, BP = (BN + 7) / 8;        // DMA pieces (8 tile rows x 128 B) per chunk
+  constexpr int A_BYTES = BM * 128, B_BYTES = ((BN + 31) / 32) * 32 * 128, STAGE = A_BYTES + B_BYTES;
+  static_assert(WTM % 16 == 0 && WTN % 16 == 0 && BM % 16 == 0 && BN % 16 == 0, "fragment multiple");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int OHW = p.OH * p.OW;
+  const int M = p.B * OHW;
+  const int nt = (p.Cout + BN - 1) / BN;
+  const int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  int tile_m, tile_n;
+  tile_of(bid, (M + BM - 1) / BM, nt, tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int ntaps = p.KH * p.KW;
+  const int cpt = p.Cin / BK;                           // chunks per filter tap
+  const int nk = ntaps * cpt;
+
+  if (wave == NW) {
+    // =========================== loader wave ===========================
+    __builtin_amdgcn_s_setprio(3);                      // its few instructions go first: the DMA of chunk k+1 starts early
+    const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+    const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
+    const char* zero = reinterpret_cast<const char*>(pf_zero_page);
+    const int lr = lane >> 3, ls = lane & 7;
+    // piece q holds tile rows 8q .. 8q+7; row = 8q + lr; source-side swizzle j = ls ^ ((row >> 1) & 7)
+    const char* a_ptr[AP];
+    unsigned a_mask[AP];
+#pragma unroll
+    for (int q = 0; q < AP; ++q) {
+      const int row = 8 * q + lr;
+      const int j = ls ^ ((row >> 1) & 7);
+      const int m = m0 + row;
+      a_mask[q] = 0u;
+      a_ptr[q] = zero;
+      if (m < M) {
+        const int b = m / OHW, rem = m - b * OHW;
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+        a_ptr[q] = reinterpret_cast<const char*>(xg + ((long)b * p.H * p.W + (long)iy0 * p.W + ix0) * p.x_ld + j * VEC);
+        unsigned mk = 0u;
+        for (int t = 0; t < ntaps; ++t) {
+          const int ky = t / p.KW, kx = t - ky * p.KW;
+          if ((unsigned)(iy0 + ky) < (unsigned)p.H && (unsigned)(ix0 + kx) < (unsigned)p.W) mk |= 1u << t;
+        }
+        a_mask[q] = mk;
+      }
+    }
+    const char* b_ptr[BP];
+#pragma unroll
+    for (int q = 0; q < BP; ++q) {
+      const int row = 8 * q + lr;
+      const int j = ls ^ ((row >> 1) & 7);
+      const int n = n0 + row;
+      b_ptr[q] = (row < BN && n < p.w_rows) ? reinterpret_cast<const char*>(wg + (long)n * p.Kpad + j * VEC) : nullptr;
+    }
+    const unsigned smem_base = lds_addr(smem);
+    int tap = 0, cc = 0, ky = 0, kx = 0;                // wave-uniform K position of the NEXT chunk to issue
+    auto issue = [&](int stage, int kc) {
+      const unsigned As = smem_base + stage * STAGE;
+      const unsigned Bs = As + A_BYTES;
+      const long koff_a = ((long)(ky * p.W + kx) * p.x_ld + (long)cc * BK) * (long)sizeof(T);
+      const long koff_b = (long)kc * (BK * (long)sizeof(T));
+#pragma unroll
+      for (int q = 0; q < AP; ++q) {
+        const bool ok = (a_mask[q] >> tap) & 1u;
+        glds16(ok ? a_ptr[q] + koff_a : zero, As + q * 1024);
+      }
+#pragma unroll
+      for (int q = 0; q < BP; ++q) glds16(b_ptr[q] ? b_ptr[q] + koff_b : zero, Bs + q * 1024);
+      if (++cc == cpt) {
+        cc = 0;
+        ++tap;
+        if (++kx == p.KW) { kx = 0; ++ky; }
+      }
+    };
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+      if (kc + 1 < nk) issue((kc + 1) & 1, kc + 1);    // lands while the compute waves multiply chunk kc
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    return;
+  }
+
+  // =========================== compute waves ===========================
+  const int wm = wave / WN, wn = wave % WN;
+  f32x4 acc[FN][FM];
+#pragma unroll
+  for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) acc[fn][fm] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fg = lane >> 4;
+  const int swz = (fr >> 1) & 7;
+  const int a_row_off = (wm * WTM + fr) * 128;  // activations (pixels)
+  const int b_row_off = (wn * WTN + fr) * 128;  // weights (channels)
+  __syncthreads();                                // chunk 0 has landed
+  for (int kc = 0; kc < nk; ++kc) {
+    const char* As = smem + (kc & 1) * STAGE;
+    const char* Bs = As + A_BYTES;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int slot = (((s << 2) | fg) ^ swz) << 4;
+      uint4 wf[FN], xf[FM];
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn) wf[fn] = *reinterpret_cast<const uint4*>(Bs + b_row_off + fn * 16 * 128 + slot);
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm) {
+        xf[fm] = *reinterpret_cast<const uint4*>(As + a_row_off + fm * 16 * 128 + slot);
+        if constexpr (RELU_IN) xf[fm] = relu_vec<T>(xf[fm]);
+      }
+      if constexpr (sizeof(T) == 2) mma_half_bf16<FM, FN>(wf, xf, acc);
+      else mma_half_f32<FM, FN>(wf, xf, acc);
+    }
+    __syncthreads();      // stage kc&1 is free again; the loader has waited for chunk kc+1
+  }
+
+  // ---- epilogue: bias -> act -> scale -> residual(s) -> store 4 consecutive channels (same order as conv_igemm_kernel) ----
+#pragma unroll
+  for (int fm = 0; fm < FM; ++fm) {
+    const int m = m0 + wm * WTM + fm * 16 + fr;
+    if (m >= M) continue;
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) {
+      const int n = n0 + wn * WTN + fn * 16 + fg * 4;
+      if (n >= p.Cout) continue;
+      float v[4] = {acc[fn][fm][0], acc[fn][fm][1], acc[fn][fm][2], acc[fn][fm][3]};
+      if (p.bias) {
+        const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+      }
+      if (p.act == PF_ACT_RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      } else if (p.act == PF_ACT_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+      } else if (p.act == PF_ACT_SOFTPLUS) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = softplus20(v[r]);
+      }
+      if (p.scale) {
+        const float4 sv = *reinterpret_cast<const float4*>(p.scale + n);
+        v[0] *= sv.x; v[1] *= sv.y; v[2] *= sv.z; v[3] *= sv.w;
+      }
+      if (p.res) {
+        float t[4];
+        load4(reinterpret_cast<const T*>(p.res) + (long)m * p.res_ld + n, t);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += t[r];
+      }
+      if (p.res2) {
+        float t[4];
+        load4(reinterpret_cast<const T*>(p.res2) + (long)m * p.res2_ld + n, t);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += t[r];
+      }
+      if (p.out_f32) store4(reinterpret_cast<float*>(p.y) + (long)m * p.y_ld + n, v[0], v[1], v[2], v[3]);
+      else store4(reinterpret_cast<T*>(p.y) + (long)m * p.y_ld + n, v[0], v[1], v[2], v[3]);
     }
   }
 }
@@ -1369,11 +1445,11 @@ int launch_halo(const pf_conv_params& p, hipStream_t st) {
 
 thread_local char g_err[256] = {0};
 
-template <typename T, int BM, int BN, int WM, int WN, bool RELU_IN, int PIPE>
+template <typename T, int BM, int BN, int WM, int WN, bool RELU_IN>
 int launch_cfg2(const pf_conv_params& p, hipStream_t st) {
-  constexpr int smem = (PIPE == 2 ? 3 : 2) * (BM + ((BN + 31) / 32) * 32) * 128;
+  constexpr int smem = 2 * (BM + ((BN + 31) / 32) * 32) * 128;
   static std::atomic<unsigned long long> attr_done{0};
-  auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, RELU_IN, PIPE>;
+  auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, RELU_IN>;
   ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
   const long M = (long)p.B * p.OH * p.OW;
   const long mt = (M + BM - 1) / BM, nt = (p.Cout + BN - 1) / BN;
@@ -1381,20 +1457,32 @@ int launch_cfg2(const pf_conv_params& p, hipStream_t st) {
   return launch_status();
 }
 
-int f32_pipe() {     // PF_F32_PIPE (read per call): K-loop pipeline of the f32 generic kernel, see conv_igemm_kernel
-  const char* e = getenv("PF_F32_PIPE");
-  return e ? atoi(e) : PF_F32_PIPE_DEFAULT;
-}
-
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_cfg(const pf_conv_params& p, hipStream_t st) {
-  if constexpr (sizeof(T) == 4 && BM * BN <= 128 * 128 && BN >= 64) {
-    const int pipe = f32_pipe();
-    if (pipe == 3) return p.relu_in ? launch_cfg2<T, BM, BN, WM, WN, true, 3>(p, st) : launch_cfg2<T, BM, BN, WM, WN, false, 3>(p, st);
-    if (pipe == 2) return p.relu_in ? launch_cfg2<T, BM, BN, WM, WN, true, 2>(p, st) : launch_cfg2<T, BM, BN, WM, WN, false, 2>(p, st);
-    if (pipe == 1) return p.relu_in ? launch_cfg2<T, BM, BN, WM, WN, true, 1>(p, st) : launch_cfg2<T, BM, BN, WM, WN, false, 1>(p, st);
-  }
-  return p.relu_in ? launch_cfg2<T, BM, BN, WM, WN, true, 0>(p, st) : launch_cfg2<T, BM, BN, WM, WN, false, 0>(p, st);
+  return p.relu_in ? launch_cfg2<T, BM, BN, WM, WN, true>(p, st) : launch_cfg2<T, BM, BN, WM, WN, false>(p, st);
+}
+
+template <typename T, int BM, int BN, int WM, int WN, bool RELU_IN>
+int launch_ws2(const pf_conv_params& p, hipStream_t st) {
+  constexpr int smem = 2 * (BM + ((BN + 31) / 32) * 32) * 128;
+  static std::atomic<unsigned long long> attr_done{0};
+  auto kern = conv_igemm_ws_kernel<T, BM, BN, WM, WN, RELU_IN>;
+  ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
+  const long M = (long)p.B * p.OH * p.OW;
+  const long mt = (M + BM - 1) / BM, nt = (p.Cout + BN - 1) / BN;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(mt * nt)), dim3(64 * (WM * WN + 1)), smem, st, p);
+  return launch_status();
+}
+template <typename T, int BM, int BN, int WM, int WN>
+int launch_ws(const pf_conv_params& p, hipStream_t st) {
+  return p.relu_in ? launch_ws2<T, BM, BN, WM, WN, true>(p, st) : launch_ws2<T, BM, BN, WM, WN, false>(p, st);
+}
+// wave-specialised kernel: f32 layers whose K chunks stay inside one filter tap.  PF_F32_WS=0 (read per call) turns it off (A/B)
+template <typename T>
+bool use_ws(const pf_conv_params& p) {
+  if (sizeof(T) != 4 || p.shuffle > 1 || p.Cin % (8 * Elem<T>::VEC)) return false;
+  const char* e = getenv("PF_F32_WS");
+  return !(e && e[0] == '0');
 }
 
 int g_force_small = -1;   // PF_IGEMM_SMALL=1 forces the 4-wave kernel everywhere (A/B measurements)
@@ -1506,6 +1594,17 @@ static int best_cfg(const pf_conv_params& p, long M, int cout, double* cost_out)
 
 template <typename T>
 int launch_generic(const pf_conv_params& p, hipStream_t st, int cfg) {
+  if constexpr (sizeof(T) == 4) {
+    if (use_ws<T>(p)) {
+      switch (cfg) {
+        case 1: return launch_ws<T, 128, 128, 2, 2>(p, st);
+        case 2: return launch_ws<T, 128, 96, 2, 2>(p, st);
+        case 3: return launch_ws<T, 128, 64, 2, 2>(p, st);
+        case 6: return launch_ws<T, 64, 64, 2, 2>(p, st);
+        default: break;
+      }
+    }
+  }
   switch (cfg) {
     case 0: if constexpr (sizeof(T) == 2) return p.relu_in ? launch_big<true>(p, st) : launch_big<false>(p, st);
     case 1: return launch_cfg<T, 128, 128, 2, 2>(p, st);

@@ -20,7 +20,7 @@ import torch
 
 from . import packing as pk
 from .config import pyramid_sizes
-from .spec import DPT_ARCH, VIT_ARCH
+from .spec import DPT_ARCH, VIT_ARCH, branch_channels
 
 F32 = torch.float32
 
@@ -266,6 +266,45 @@ class BranchNet:
         return depth, [x_d0, r4, r3, r2, r1, out_conv]
 
 
+class ExternalCoreBranchNet:
+    """ZoeDepth branch whose relative-depth core is EXTERNAL (type 'ZoeDepth': MiDaS DPT_BEiT_L_384, BASELINE configs[4]).
+
+    The MiDaS/BEiT core is not in the reference tree (torch.hub repo AyaanShah2204/MiDaS, no commit pinned, midas.py:340), so
+    it is supplied as a feature provider -- the reference's own injection point ``ZoeDepth.forward(hack_feature=(rel_depth,
+    out))`` (zoedepth_v1.py:160-166):
+        provider(img [B,3,H,W] float32 in [0,1]) -> (rel_depth [B,H,W] f32, [btlnck, x_block0..3, out_conv] NCHW f32)
+    with btlnck at H/32 and the blocks at H/16 ... H/2 (256 channels), out_conv 32 channels at HxW.  Everything after the core --
+    conv2 and the metric-bins head (zoedepth_v1.py:170-219) -- runs on the HIP op set exactly like the Depth-Anything branch."""
+
+    def __init__(self, sd, prefix, bcfg, process_shape, dtype, device, provider):
+        if provider is None:
+            raise NotImplementedError(
+                "branch type 'ZoeDepth' needs a relative-depth core: the MiDaS/BEiT encoder is an un-vendored torch.hub "
+                "repository (midas.py:340).  Pass core_providers=(coarse, fine) to PatchFusion or call set_core_providers().")
+        self.dtype, self.device, self.provider = dtype, device, provider
+        self.C = branch_channels(bcfg)
+        self.H, self.W = process_shape
+        self.conv2 = pk.pack_conv(sd[prefix + "conv2.weight"], sd[prefix + "conv2.bias"], dtype=dtype).to(device)
+        self.head = BinsHead(sd, prefix, self.C, bcfg, dtype, device, with_rel=True)
+
+    def forward(self, ops, img, taps=None):
+        dt, dev = self.dtype, self.device
+        rel, feats = self.provider(img)
+        assert len(feats) == 6, "provider must return [btlnck, x_block0..3, out_conv]"
+        nhwc = [f.detach().to(dev).permute(0, 2, 3, 1).contiguous().to(dt) for f in feats]      # re-layout only
+        btl, blocks, outc = nhwc[0], nhwc[1:5], nhwc[5]
+        B, H, W = rel.shape
+        clb = self.head.new_clb_buffer(ops, B, H, W)            # [last 0..31 | emb 32..159 | rel 160 (+7 zero pad)]
+        ops.copy_channels(outc, clb[..., :32])
+        tail = torch.zeros((B, H, W, 8), dtype=dt, device=dev)
+        tail[..., 0] = rel.detach().to(device=dev, dtype=dt)
+        clb[..., 32 + self.head.emb:] = tail
+        x_d0 = ops.empty(btl.shape[:3] + (self.C,), dt, dev)
+        ops.conv(btl, self.conv2, x_d0)
+        depth = self.head.run(ops, x_d0, blocks, clb, taps)
+        return depth, [x_d0] + blocks + [clb[..., :32]]
+
+
 class G2LNet:
     """The six global-to-local Swin stacks; input = whole-image coarse pyramid, i.e. patch invariant."""
     DEPTH = [4, 4, 3, 3, 2, 2]     # guided_fusion_model.py:109-110 defaults, reversed at :141-143
@@ -273,7 +312,8 @@ class G2LNet:
 
     def __init__(self, sd, gcfg, dtype, device, prefix="guided_fusion."):
         self.dtype, self.device = dtype, device
-        ch = list(gcfg["in_channels"])[::-1]
+        from .spec import GF_DEFAULT_IN_CHANNELS
+        ch = list(gcfg.get("in_channels", GF_DEFAULT_IN_CHANNELS))[::-1]
         self.levels = []
         for i, C in enumerate(ch):
             g = f"{prefix}g2l_list.{i}."
@@ -333,9 +373,9 @@ class FusionNet:
     def __init__(self, sd, cfg, dtype, device):
         self.dtype, self.device = dtype, device
         fb = cfg["fine_branch"]
-        self.C = DPT_ARCH[fb["midas_model_type"]][0]
+        self.C = branch_channels(fb)
         self.ps = tuple(cfg["patch_process_shape"])
-        self.sizes = pyramid_sizes(self.ps)[::-1]                   # L0..L5 (h, w)
+        self.sizes = pyramid_sizes(self.ps, fb["type"])[::-1]       # L0..L5 (h, w)
         self.ch = [self.C] * 5 + [32]                               # channels per level L0..L5
         g = "guided_fusion."
 

@@ -104,7 +104,7 @@ def _build_param_tree(root, spec):
 
 
 class PatchFusion(nn.Module, PyTorchModelHubMixin):
-    def __init__(self, config, compute_dtype=None, ops=None, shard_patches=None):
+    def __init__(self, config, compute_dtype=None, ops=None, shard_patches=None, core_providers=None):
         nn.Module.__init__(self)
         # patchfusion.py:64-78: an mmengine ConfigDict (tools/test.py, tools/train.py) forces load_branch=True; any
         # other mapping (the HF `from_pretrained` path hands over a plain dict read from config.json, which was
@@ -128,15 +128,24 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
                 if br.midas_model_type not in ('vits', 'vitb', 'vitl'):
                     raise NotImplementedError(br.midas_model_type)
             elif br.type == 'ZoeDepth':
-                # BEiT/MiDaS encoder lives in an un-vendored torch.hub repo (midas.py:340): parity unpinned
-                raise NotImplementedError("ZoeDepth (MiDaS BEiT) branch is not built yet; see DESIGN.md out-of-scope")
+                # MiDaS-core branch (BASELINE configs[4]): the BEiT/MiDaS core lives in an un-vendored torch.hub repo
+                # (midas.py:340) and is supplied as a feature provider (engine.ExternalCoreBranchNet, PARITY UNPINNED for
+                # the core); the ZoeDepth head, the fusion network and the tiling run on the HIP engine
+                from .spec import MIDAS_CORE_CHANNELS
+                if br.midas_model_type not in MIDAS_CORE_CHANNELS:
+                    raise ValueError(f"Invalid model type: {br.midas_model_type}. Must be one of {list(MIDAS_CORE_CHANNELS)}")
             else:
                 raise NotImplementedError
+        if config.coarse_branch.type != config.fine_branch.type:
+            raise NotImplementedError("coarse and fine branch of different types")
         if config.coarse_branch.bin_centers_type != "softplus":
             if config.coarse_branch.bin_centers_type in ("normed", "hybrid1", "hybrid2"):
                 raise NotImplementedError("only bin_centers_type='softplus' (the shipped configs) is built")
             raise ValueError("bin_centers_type should be one of 'normed', 'softplus', 'hybrid1', 'hybrid2'")
-        self.resizer = Resizer(self.patch_process_shape[1], self.patch_process_shape[0], 14)
+        # patchfusion.py:82-87: ensure_multiple_of 32 for the MiDaS-core branch, 14 for Depth-Anything
+        self.resizer = Resizer(self.patch_process_shape[1], self.patch_process_shape[0],
+                               32 if config.coarse_branch.type == 'ZoeDepth' else 14)
+        self.core_providers = tuple(core_providers) if core_providers is not None else (None, None)
         self.spec = patchfusion_spec(config)
         _build_param_tree(self, self.spec)
         self.consistency_training = False
@@ -186,6 +195,11 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
     def get_save_dict(self):
         return OrderedDict((k, v) for k, v in self.state_dict().items() if 'coarse_branch' not in k and 'fine_branch' not in k)
 
+    def set_core_providers(self, coarse, fine):
+        """relative-depth cores of a type-'ZoeDepth' model (see engine.ExternalCoreBranchNet)"""
+        self.core_providers = (coarse, fine)
+        self._engine = None
+
     def set_compute_dtype(self, dtype):
         self.compute_dtype = _DTYPES[dtype]
         self._engine = None
@@ -200,15 +214,19 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
 
     def _ensure_engine(self):
         if self._engine is None:
-            from .engine import BranchNet, FusionNet, G2LNet
+            from .engine import BranchNet, ExternalCoreBranchNet, FusionNet, G2LNet
             sd = self.state_dict()
             dev = next(iter(sd.values())).device
             if self._ops is None and dev.type != "cuda":
                 raise RuntimeError("PatchFusion (MI355X engine) needs the model on a GPU: call .cuda() first")
             dt, cfg = self.compute_dtype, self.config
+            def branch(prefix, bcfg, provider):
+                if bcfg.type == 'ZoeDepth':
+                    return ExternalCoreBranchNet(sd, prefix, bcfg, self.patch_process_shape, dt, dev, provider)
+                return BranchNet(sd, prefix, bcfg, self.patch_process_shape, dt, dev)
             self._engine = dict(
-                coarse=BranchNet(sd, "coarse_branch.", cfg.coarse_branch, self.patch_process_shape, dt, dev),
-                fine=BranchNet(sd, "fine_branch.", cfg.fine_branch, self.patch_process_shape, dt, dev),
+                coarse=branch("coarse_branch.", cfg.coarse_branch, self.core_providers[0]),
+                fine=branch("fine_branch.", cfg.fine_branch, self.core_providers[1]),
                 g2l=G2LNet(sd, cfg.guided_fusion, dt, dev),
                 fusion=FusionNet(sd, cfg, dt, dev))
             self._device = dev

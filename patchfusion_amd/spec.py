@@ -135,19 +135,41 @@ def bins_head_spec(d, p, C, n_bins, emb, n_attractors):
     _conv(d, p + "conditional_log_binomial.mlp.2", 4, cin // 2, 1)
 
 
+MIDAS_CORE_CHANNELS = {
+    # external/zoedepth/models/base_models/midas.py:368-376 (MIDAS_SETTINGS): btlnck + 4 decoder levels
+    "DPT_BEiT_L_384": 256, "DPT_BEiT_L_512": 256, "DPT_BEiT_B_384": 256, "DPT_SwinV2_L_384": 256, "DPT_SwinV2_B_384": 256,
+    "DPT_SwinV2_T_256": 256, "DPT_Large": 256, "DPT_Hybrid": 256,
+}
+
+
+def branch_channels(bcfg):
+    """feature channels C of a branch's five decoder levels (the sixth, `out_conv`, always has N_MIDAS_OUT = 32)"""
+    if bcfg["type"] == "DA-ZoeDepth":
+        return DPT_ARCH[bcfg["midas_model_type"]][0]
+    return MIDAS_CORE_CHANNELS[bcfg["midas_model_type"]]
+
+
 def branch_spec(d, p, bcfg):
-    enc = bcfg["midas_model_type"]
-    C = DPT_ARCH[enc][0]
-    vit_spec(d, p + "core.core.pretrained.", enc)
-    dpt_head_spec(d, p + "core.core.depth_head.", enc)
+    """type 'DA-ZoeDepth': DINOv2 ViT + DPT core + ZoeDepth head.  type 'ZoeDepth' (MiDaS core, BASELINE configs[4]): only
+    the ZoeDepth head is specified here -- the MiDaS/BEiT core lives in an un-vendored torch.hub repository (midas.py:340) and is
+    supplied by a feature provider (engine.ExternalCoreBranchNet); its `core.*` checkpoint keys are not part of the schema."""
+    C = branch_channels(bcfg)
+    if bcfg["type"] == "DA-ZoeDepth":
+        enc = bcfg["midas_model_type"]
+        vit_spec(d, p + "core.core.pretrained.", enc)
+        dpt_head_spec(d, p + "core.core.depth_head.", enc)
     _conv(d, p + "conv2", C, C, 1)
     bins_head_spec(d, p, C, bcfg["n_bins"], bcfg["bin_embedding_dim"], bcfg["n_attractors"])
 
 
+GF_DEFAULT_IN_CHANNELS = [32, 256, 256, 256, 256, 256]                      # guided_fusion_model.py:108
+GF_DEFAULT_NUM_PATCHES = [384 * 512, 192 * 256, 96 * 128, 48 * 64, 24 * 32, 12 * 16]  # guided_fusion_model.py:112
+
+
 def guided_fusion_spec(d, p, gcfg):
-    ch = list(gcfg["in_channels"])                      # [32, C, C, C, C, C]
+    ch = list(gcfg.get("in_channels", GF_DEFAULT_IN_CHANNELS))                      # [32, C, C, C, C, C]
     n_in = gcfg.get("n_channels", 5)
-    num_patches = list(gcfg["num_patches"])
+    num_patches = list(gcfg.get("num_patches", GF_DEFAULT_NUM_PATCHES))
     depth = list(gcfg.get("depth", G2L_DEPTH))
     heads = list(gcfg.get("num_heads", G2L_HEADS))
 
@@ -197,7 +219,7 @@ def patchfusion_spec(cfg):
     cb, fb = cfg["coarse_branch"], cfg["fine_branch"]
     branch_spec(d, "coarse_branch.", cb)
     branch_spec(d, "fine_branch.", fb)
-    C = DPT_ARCH[fb["midas_model_type"]][0]
+    C = branch_channels(fb)
     for i in range(6):
         if i == 5:
             _conv(d, f"fusion_conv_list.{i}", N_MIDAS_OUT, 2 * N_MIDAS_OUT, 3)

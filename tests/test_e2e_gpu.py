@@ -176,3 +176,33 @@ def test_baseline_pretrain_fine_and_coarse_vs_oracle():
         d, _ = m(mode="infer", image_lr=lr.cuda(), image_hr=img.cuda(), cai_mode=mode, process_num=2)
         o = pf_oracle.BaselineOracle(bc, ps, raw, split, sd, target).infer(lr, img, mode, 2)
         assert d.shape == o.shape and float((d.cpu() - o).abs().max()) < 2e-4, (target, float((d.cpu() - o).abs().max()))
+
+
+def test_zoe_midas_core_geometry_r_mode_vs_oracle():
+    """BASELINE configs[4], encoder-independent part on the HIP engine at the real 384x512 geometry (multiple-of-32 resize,
+    GuidedFusion default pyramid 12x16 ... 384x512, C=256) with random tiles (`r4`, 13 patches): ZoeDepth head + fusion net +
+    tiling vs the oracle, both fed by the same stand-in relative-depth core (tests/zoe_core_standin.py; the MiDaS/BEiT core
+    itself is an un-vendored torch.hub repo -> PARITY UNPINNED)."""
+    from patchfusion_amd.config import make_zoe_config
+    from tests.zoe_core_standin import StandInCore
+    cfg = make_zoe_config((384, 512), (1536, 2048), (2, 2))
+    sd = synthetic_state_dict(patchfusion_spec(cfg), 0)
+    cores = (StandInCore(11), StandInCore(12))
+    img = torch.rand(1, 3, 1536, 2048, generator=torch.Generator().manual_seed(1234)).cuda()
+    sdg = {k: v.cuda() for k, v in sd.items()}
+    for dtype, tol in (("fp32", 2e-4), ("bf16", 1e-2)):
+        m = PatchFusion(cfg, compute_dtype=dtype, core_providers=cores).eval()
+        m.load_state_dict(sd, strict=True)
+        m = m.cuda()
+        lr = m.resizer(img)
+        assert tuple(lr.shape) == (1, 3, 384, 512)
+        random.seed(5621)
+        d, _ = m(mode="infer", image_lr=lr, image_hr=img, cai_mode="r4", process_num=2)
+        random.seed(5621)
+        ref = pf_oracle.Oracle(cfg, sdg, core_providers=cores).infer(lr, img, "r4", 2)
+        assert d.shape == ref.shape == (1, 1, 1536, 2048)
+        err = float((d - ref).abs().max())
+        print(f"MEASURED zoe-geometry r4 {dtype} vs oracle: max {err:.3e} mean {float((d - ref).abs().mean()):.3e} std(ref) {float(ref.std()):.3e}")
+        assert err <= tol, (dtype, err)
+        del m
+        torch.cuda.empty_cache()

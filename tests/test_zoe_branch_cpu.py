@@ -1,0 +1,71 @@
+"""BASELINE configs[4] (ZoeDepth-N PatchFusion: MiDaS/BEiT core + metric-bins head, 384x512 geometry, `r<N>` random tiles),
+the encoder-independent part: engine wiring (torch stand-in ops, tests/fake_ops.py) against the oracle with the SAME stand-in
+relative-depth core injected on both sides (tests/zoe_core_standin.py; the core itself is PARITY UNPINNED)."""
+import random
+
+import pytest
+import torch
+
+from oracle import pf_oracle
+from patchfusion_amd import tiling
+from patchfusion_amd.config import make_zoe_config, pyramid_sizes
+from patchfusion_amd.model import PatchFusion
+from patchfusion_amd.spec import patchfusion_spec, synthetic_state_dict
+from tests.fake_ops import ops as fake_ops
+from tests.zoe_core_standin import StandInCore
+
+PS, RAW, SPLIT = (96, 128), (384, 512), (2, 2)
+
+
+@pytest.fixture(scope="module")
+def zoe():
+    cfg = make_zoe_config(PS, RAW, SPLIT)
+    sd = synthetic_state_dict(patchfusion_spec(cfg), 0)
+    cores = (StandInCore(11), StandInCore(12))
+    m = PatchFusion(cfg, compute_dtype="fp32", ops=fake_ops, core_providers=cores).eval()
+    m.load_state_dict(sd, strict=True)
+    img = torch.rand(1, 3, *RAW, generator=torch.Generator().manual_seed(1234))
+    return cfg, sd, cores, m, img
+
+
+def test_zoe_geometry_and_schema():
+    cfg = make_zoe_config()                                    # the shipped 384x512 config: fusion geometry from the class defaults
+    assert "in_channels" not in cfg["guided_fusion"]
+    spec = patchfusion_spec(cfg)
+    assert spec["guided_fusion.g2l_list.0.absolute_pos_embed"].shape == (1, 12 * 16, 256)
+    assert spec["guided_fusion.g2l_list.5.absolute_pos_embed"].shape == (1, 384 * 512, 32)
+    assert spec["coarse_branch.conv2.weight"].shape == (256, 256, 1, 1) and "coarse_branch.core.core.pretrained.cls_token" not in spec
+    assert pyramid_sizes((384, 512), "ZoeDepth") == [(384, 512), (192, 256), (96, 128), (48, 64), (24, 32), (12, 16)]
+    m = PatchFusion(cfg, ops=fake_ops)
+    # midas.py:171-173 / patchfusion.py:84: Resize(..., ensure_multiple_of=32)
+    assert m.resizer.m == 32 and m.resizer.get_size(3840, 2160) == (512, 384)
+    assert tuple(m.resizer(torch.zeros(1, 3, 540, 960)).shape) == (1, 3, 384, 512)
+    # docs/user_infer.md: 4x4 split, r128 -> 16 + 33 + 128 = 177 patches
+    random.seed(0)
+    assert len(tiling.tile_schedule(m.tile_cfg, m.patch_process_shape, "r128", 4)) == 177
+    with pytest.raises(NotImplementedError, match="relative-depth core"):
+        m(mode="infer", image_lr=torch.zeros(1, 3, 384, 512), image_hr=torch.zeros(1, 3, 2160, 3840))
+
+
+@pytest.mark.parametrize("mode", ["m1", "r4"])
+def test_zoe_patchfusion_matches_oracle_with_injected_core(zoe, mode):
+    cfg, sd, cores, m, img = zoe
+    lr = m.resizer(img)
+    random.seed(5621)
+    with torch.no_grad():
+        d, _ = m(mode="infer", image_lr=lr, image_hr=img, cai_mode=mode, process_num=2)
+    random.seed(5621)
+    ref = pf_oracle.Oracle(cfg, sd, core_providers=cores).infer(lr, img, mode, 2)
+    assert d.shape == ref.shape
+    assert float((d - ref).abs().max()) < 2e-5, float((d - ref).abs().max())
+    assert float(ref.std()) > 1e-3                             # the map is not trivially constant
+
+
+def test_zoe_branch_features_match_oracle(zoe):
+    cfg, sd, cores, m, img = zoe
+    lr = m.resizer(img)
+    depth, feats = m.coarse_forward(lr)
+    od, of = pf_oracle.branch_forward_external(sd, "coarse_branch.", lr, cfg["coarse_branch"], cores[0])
+    assert float((depth - od).abs().max()) < 1e-5
+    for a, b in zip(feats, of):
+        assert a.shape == b.shape and float((a - b).abs().max()) < 1e-5

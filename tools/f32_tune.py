@@ -1,5 +1,5 @@
 """Kernel-tuning aid: time the f32 generic implicit-GEMM kernel on the FLOP-carrying shapes for every
-(K-loop pipeline PF_F32_PIPE, tile PF_IGEMM_CFG) combination in ONE process and check that every variant is
+(wave-specialised loader on/off PF_F32_WS, tile PF_IGEMM_CFG) combination in ONE process and check that every variant is
 BIT-IDENTICAL to the default (same K order per output element, so any difference is a bug).
 usage: python tools/f32_tune.py [out.json]"""
 import json
@@ -23,9 +23,9 @@ for name, (B, H, W), cin, cout, k in SHAPES:
     pw = pk.pack_conv(w, torch.randn(cout, generator=g), dtype=torch.float32).to(dev)
     fl = 2.0 * B * H * W * cin * k * k * cout
     ref = None
-    for pipe in ("0", "3"):
+    for pipe in ("0", "1"):
         for cfg in ("", "1", "2", "3", "6"):
-            os.environ["PF_F32_PIPE"] = pipe
+            os.environ["PF_F32_WS"] = pipe
             if cfg:
                 os.environ["PF_IGEMM_CFG"] = cfg
             else:
@@ -38,12 +38,12 @@ for name, (B, H, W), cin, cout, k in SHAPES:
                 same = True
             else:
                 same = bool(torch.equal(y, ref))
-            r = dict(shape=name, pipe=int(pipe), cfg=cfg or "auto", ms=ms, tflops=fl / ms / 1e9, frac=fl / ms / 1e9 / 157.3, bit_identical=same)
+            r = dict(shape=name, ws=int(pipe), cfg=cfg or "auto", ms=ms, tflops=fl / ms / 1e9, frac=fl / ms / 1e9 / 157.3, bit_identical=same)
             res.append(r)
-            print(f"{name:10s} pipe {pipe} cfg {cfg or 'auto':4s}: {ms:8.3f} ms {r['tflops']:7.1f} TF/s ({100 * r['frac']:.1f} %)  {'==' if same else 'DIFFERENT'}", flush=True)
+            print(f"{name:10s} ws {pipe} cfg {cfg or 'auto':4s}: {ms:8.3f} ms {r['tflops']:7.1f} TF/s ({100 * r['frac']:.1f} %)  {'==' if same else 'DIFFERENT'}", flush=True)
             del y
     del x, ref
 os.environ.pop("PF_IGEMM_CFG", None)
-os.environ.pop("PF_F32_PIPE", None)
+os.environ.pop("PF_F32_WS", None)
 if len(sys.argv) > 1:
     json.dump(res, open(sys.argv[1], "w"), indent=0)

@@ -53,6 +53,7 @@ typedef struct {
   int out_f32;   /* store float32 even when dtype == bf16 (bins-head tensors) */
   int shuffle;   /* s>1: ConvTranspose2d(kernel=stride=s): N = s*s*Cout_t, y is [B,OH*s,OW*s,Cout_t] */
   int dtype;
+  int korder;    /* K order of w: 0 = (ky,kx,c); 1 = (c/32, ky, kx, c%32), f32 only, Cin % 32 == 0 (see packing.py) */
 } pf_conv_params;
 int pf_conv(const pf_conv_params* p, void* stream);
 /* timing helper for the roofline entry of bench.py: runs `iters` launches bracketed by HIP events on
@@ -101,6 +102,11 @@ int pf_add_rowwise(void* x, int x_ld, const float* pos, int B, int T, int C, int
  * y[b,oy,ox, 0..C) = (add ? add[...] : 0) + interp(x).  NHWC both sides. */
 int pf_resize_bilinear(const void* x, int x_ld, int B, int H, int W, int C, void* y, int y_ld, int OH, int OW,
                        const void* add, int add_ld, int in_f32, int out_f32, int dtype, void* stream);
+/* nsrc (2 or 3) bilinear align_corners=True resizes of NHWC tensors xs[i] [B,Hs[i],Ws[i],Cs[i]] (pixel stride lds[i]) written to
+ * consecutive channel ranges of y [B,OH,OW, sum Cs] (pixel stride y_ld): the Upv1 concat of guided_fusion_model.py:96-99
+ * (cat[feat_enc_resized, up(temp), up(guide)]) in one launch.  All tensors in `dtype`.  The five arrays are HOST arrays. */
+int pf_resize_concat(const void* const* xs, const int* lds, const int* Hs, const int* Ws, const int* Cs, int nsrc, int B,
+                     void* y, int y_ld, int OH, int OW, int dtype, void* stream);
 /* planar float version for the image crops (depth_anything/transform.py:127-129 applied per tile,
  * baseline_pretrain.py:258-264): img [3][H][W] float -> out [P][3][oh][ow] float; boxes int [P][4]=(x0,y0,x1,y1) */
 int pf_crop_resize_planar(const float* img, int C, int H, int W, const int* boxes, int P, float* out, int oh, int ow,

@@ -21,7 +21,7 @@ class ConvParams(C.Structure):
         ("res", vp), ("res_ld", ci), ("res2", vp), ("res2_ld", ci),
         ("y", vp), ("y_ld", ci), ("OH", ci), ("OW", ci), ("Cout", ci),
         ("KH", ci), ("KW", ci), ("stride", ci), ("pad", ci),
-        ("act", ci), ("relu_in", ci), ("out_f32", ci), ("shuffle", ci), ("dtype", ci),
+        ("act", ci), ("relu_in", ci), ("out_f32", ci), ("shuffle", ci), ("dtype", ci), ("korder", ci),
     ]
 
 
@@ -39,6 +39,7 @@ SIGNATURES = {
     "pf_swin_unpartition_add": [vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp],
     "pf_add_rowwise": [vp, ci, vp, ci, ci, ci, ci, vp],
     "pf_resize_bilinear": [vp, ci, ci, ci, ci, ci, vp, ci, ci, ci, vp, ci, ci, ci, ci, vp],
+    "pf_resize_concat": [C.POINTER(vp), C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), ci, ci, vp, ci, ci, ci, ci, vp],
     "pf_crop_resize_planar": [vp, ci, ci, ci, vp, ci, vp, ci, ci, vp],
     "pf_roi_align": [vp, ci, ci, ci, ci, ci, vp, ci, vp, ci, ci, ci, cf, ci, ci, ci, vp],
     "pf_maxpool2": [vp, ci, ci, ci, ci, ci, vp, ci, ci, vp],

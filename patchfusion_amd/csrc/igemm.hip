@@ -176,7 +176,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
   const int nk = (ntaps * cin_v + 7) / 8;
 #endif
   // this thread's K position: vector index kv = kc*8 + j  ->  (tap = (ky,kx), cv)
-  int tap = j / cin_v, cv = j - tap * cin_v;
+  // korder 1 (chunk-major weights): chunk kc is tap kc % ntaps of channel chunk kc / ntaps -> cv = 8 (kc / ntaps) + j
+  int tap = p.korder ? 0 : j / cin_v, cv = j - tap * cin_v;
   int ky = tap / p.KW, kx = tap - ky * p.KW;
 
   const unsigned smem_base = lds_addr(smem);
@@ -227,11 +228,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
       glds16(src, Bs + i * (32 * 128));
     }
     // advance this thread's K position by one chunk (8 vectors)
-    cv += 8;
-    while (cv >= cin_v) {
-      cv -= cin_v;
-      ++tap;
+    if (p.korder) {
       if (++kx == p.KW) { kx = 0; ++ky; }
+      if (++tap == ntaps) { tap = 0; ky = 0; kx = 0; cv += 8; }
+    } else {
+      cv += 8;
+      while (cv >= cin_v) {
+        cv -= cin_v;
+        ++tap;
+        if (++kx == p.KW) { kx = 0; ++ky; }
+      }
     }
   };
 
@@ -375,194 +381,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
 }
 
 // -------------------------------------------------------------------------------------------------
-// WAVE-SPECIALISED variant of conv_igemm_kernel: WM*WN compute waves + ONE loader wave (the last wave of the block).
-// Why (profiles/r2_abl_f32.log, f32 3x3 768->768 @ 8x224x296): the kernel above runs at 132.9 TF/s; the same kernel
-// without its in-loop LDS-DMA runs at 148.2 (94 % of the f32 MFMA peak), without barrier 134.7, without LDS reads 128.9.
-// A wave is in-order: every global_load_lds it issues costs it ~100 cycles of issue time (MI355X_MICROARCH.md "LDS-DMA
-// piece issue cost") during which it cannot feed the matrix pipe, and three-stage rings / more blocks per CU / DMA pieces
-// interleaved between MFMA groups all measured WORSE (profiles/r2_f32_tune*.log).  So the compute waves issue no VMEM at
-// all in the K loop: the loader wave owns every DMA instruction of the block (BM/8 + BN/8 pieces of 8 rows x 128 B per
-// chunk, ~32 x 100 cycles against a chunk period of 2 x 4096 MFMA cycles with two co-resident blocks), waits for them
-// (vmcnt) and meets the compute waves at the one barrier per chunk.  Same LDS image, same source-side swizzle, same
-// K order per output element -> results are bit-identical to conv_igemm_kernel.
-// Requirements (dispatcher): Cin % BK == 0 (a chunk never straddles two filter taps, so tap / ky / kx are wave-uniform),
-// shuffle <= 1.
-// -------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WM, int WN, bool RELU_IN>
-__global__ __launch_bounds__(64 * (WM * WN + 1), 3) void conv_igemm_ws_kernel(const pf_conv_params p) {
-  constexpr int VEC = Elem<T>::VEC;
-  constexpr int BK = 8 * VEC;
-  constexpr int NW = WM * WN;                           // compute waves
-  constexpr int WTM = BM / WM, WTN = BN / WN;
-  constexpr int FM = WTM / 16, FN = WTN / 16;
-  constexpr int AP = BM / 8, BP = (BN + 7) / 8;        // DMA pieces (8 tile rows x 128 B) per chunk
-  constexpr int A_BYTES = BM * 128, B_BYTES = ((BN + 31) / 32) * 32 * 128, STAGE = A_BYTES + B_BYTES;
-  static_assert(WTM % 16 == 0 && WTN % 16 == 0 && BM % 16 == 0 && BN % 16 == 0, "fragment multiple");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int OHW = p.OH * p.OW;
-  const int M = p.B * OHW;
-  const int nt = (p.Cout + BN - 1) / BN;
-  const int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-  int tile_m, tile_n;
-  tile_of(bid, (M + BM - 1) / BM, nt, tile_m, tile_n);
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int ntaps = p.KH * p.KW;
-  const int cpt = p.Cin / BK;                           // chunks per filter tap
-  const int nk = ntaps * cpt;
-
-  if (wave == NW) {
-    // =========================== loader wave ===========================
-    __builtin_amdgcn_s_setprio(3);                      // its few instructions go first: the DMA of chunk k+1 starts early
-    const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
-    const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
-    const char* zero = reinterpret_cast<const char*>(pf_zero_page);
-    const int lr = lane >> 3, ls = lane & 7;
-    // piece q holds tile rows 8q .. 8q+7; row = 8q + lr; source-side swizzle j = ls ^ ((row >> 1) & 7)
-    const char* a_ptr[AP];
-    unsigned a_mask[AP];
-#pragma unroll
-    for (int q = 0; q < AP; ++q) {
-      const int row = 8 * q + lr;
-      const int j = ls ^ ((row >> 1) & 7);
-      const int m = m0 + row;
-      a_mask[q] = 0u;
-      a_ptr[q] = zero;
-      if (m < M) {
-        const int b = m / OHW, rem = m - b * OHW;
-        const int oy = rem / p.OW, ox = rem - oy * p.OW;
-        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
-        a_ptr[q] = reinterpret_cast<const char*>(xg + ((long)b * p.H * p.W + (long)iy0 * p.W + ix0) * p.x_ld + j * VEC);
-        unsigned mk = 0u;
-        for (int t = 0; t < ntaps; ++t) {
-          const int ky = t / p.KW, kx = t - ky * p.KW;
-          if ((unsigned)(iy0 + ky) < (unsigned)p.H && (unsigned)(ix0 + kx) < (unsigned)p.W) mk |= 1u << t;
-        }
-        a_mask[q] = mk;
-      }
-    }
-    const char* b_ptr[BP];
-#pragma unroll
-    for (int q = 0; q < BP; ++q) {
-      const int row = 8 * q + lr;
-      const int j = ls ^ ((row >> 1) & 7);
-      const int n = n0 + row;
-      b_ptr[q] = (row < BN && n < p.w_rows) ? reinterpret_cast<const char*>(wg + (long)n * p.Kpad + j * VEC) : nullptr;
-    }
-    const unsigned smem_base = lds_addr(smem);
-    int tap = 0, cc = 0, ky = 0, kx = 0;                // wave-uniform K position of the NEXT chunk to issue
-    auto issue = [&](int stage, int kc) {
-      const unsigned As = smem_base + stage * STAGE;
-      const unsigned Bs = As + A_BYTES;
-      const long koff_a = ((long)(ky * p.W + kx) * p.x_ld + (long)cc * BK) * (long)sizeof(T);
-      const long koff_b = (long)kc * (BK * (long)sizeof(T));
-#pragma unroll
-      for (int q = 0; q < AP; ++q) {
-        const bool ok = (a_mask[q] >> tap) & 1u;
-        glds16(ok ? a_ptr[q] + koff_a : zero, As + q * 1024);
-      }
-#pragma unroll
-      for (int q = 0; q < BP; ++q) glds16(b_ptr[q] ? b_ptr[q] + koff_b : zero, Bs + q * 1024);
-      if (++cc == cpt) {
-        cc = 0;
-        ++tap;
-        if (++kx == p.KW) { kx = 0; ++ky; }
-      }
-    };
-    issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int kc = 0; kc < nk; ++kc) {
-      if (kc + 1 < nk) issue((kc + 1) & 1, kc + 1);    // lands while the compute waves multiply chunk kc
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
-    return;
-  }
-
-  // =========================== compute waves ===========================
-  const int wm = wave / WN, wn = wave % WN;
-  f32x4 acc[FN][FM];
-#pragma unroll
-  for (int fn = 0; fn < FN; ++fn)
-#pragma unroll
-    for (int fm = 0; fm < FM; ++fm) acc[fn][fm] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int fr = lane & 15, fg = lane >> 4;
-  const int swz = (fr >> 1) & 7;
-  const int a_row_off = (wm * WTM + fr) * 128;  // activations (pixels)
-  const int b_row_off = (wn * WTN + fr) * 128;  // weights (channels)
-  __syncthreads();                                // chunk 0 has landed
-  for (int kc = 0; kc < nk; ++kc) {
-    const char* As = smem + (kc & 1) * STAGE;
-    const char* Bs = As + A_BYTES;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int slot = (((s << 2) | fg) ^ swz) << 4;
-      uint4 wf[FN], xf[FM];
-#pragma unroll
-      for (int fn = 0; fn < FN; ++fn) wf[fn] = *reinterpret_cast<const uint4*>(Bs + b_row_off + fn * 16 * 128 + slot);
-#pragma unroll
-      for (int fm = 0; fm < FM; ++fm) {
-        xf[fm] = *reinterpret_cast<const uint4*>(As + a_row_off + fm * 16 * 128 + slot);
-        if constexpr (RELU_IN) xf[fm] = relu_vec<T>(xf[fm]);
-      }
-      if constexpr (sizeof(T) == 2) mma_half_bf16<FM, FN>(wf, xf, acc);
-      else mma_half_f32<FM, FN>(wf, xf, acc);
-    }
-    __syncthreads();      // stage kc&1 is free again; the loader has waited for chunk kc+1
-  }
-
-  // ---- epilogue: bias -> act -> scale -> residual(s) -> store 4 consecutive channels (same order as conv_igemm_kernel) ----
-#pragma unroll
-  for (int fm = 0; fm < FM; ++fm) {
-    const int m = m0 + wm * WTM + fm * 16 + fr;
-    if (m >= M) continue;
-#pragma unroll
-    for (int fn = 0; fn < FN; ++fn) {
-      const int n = n0 + wn * WTN + fn * 16 + fg * 4;
-      if (n >= p.Cout) continue;
-      float v[4] = {acc[fn][fm][0], acc[fn][fm][1], acc[fn][fm][2], acc[fn][fm][3]};
-      if (p.bias) {
-        const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-      }
-      if (p.act == PF_ACT_RELU) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-      } else if (p.act == PF_ACT_GELU) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-      } else if (p.act == PF_ACT_SOFTPLUS) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = softplus20(v[r]);
-      }
-      if (p.scale) {
-        const float4 sv = *reinterpret_cast<const float4*>(p.scale + n);
-        v[0] *= sv.x; v[1] *= sv.y; v[2] *= sv.z; v[3] *= sv.w;
-      }
-      if (p.res) {
-        float t[4];
-        load4(reinterpret_cast<const T*>(p.res) + (long)m * p.res_ld + n, t);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += t[r];
-      }
-      if (p.res2) {
-        float t[4];
-        load4(reinterpret_cast<const T*>(p.res2) + (long)m * p.res2_ld + n, t);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += t[r];
-      }
-      if (p.out_f32) store4(reinterpret_cast<float*>(p.y) + (long)m * p.y_ld + n, v[0], v[1], v[2], v[3]);
-      else store4(reinterpret_cast<T*>(p.y) + (long)m * p.y_ld + n, v[0], v[1], v[2], v[3]);
-    }
-  }
-}
-
-// -------------------------------------------------------------------------------------------------
-// EXPERIMENTAL (opt-in: PF_GEMM_PERSIST=1; not dispatched by default, see DESIGN.md 4a "next"): persistent variant of
-// the 1x1 / linear fast path of conv_igemm_kernel for bf16.  The measured life of a K=1024 ViT linear block is only
+// Persistent variant of the 1x1 / linear fast path of conv_igemm_kernel for bf16 (default for Cout >= 2048, PF_GEMM_PERSIST=0
+// turns it off, =1 / a shape code forces it for every eligible layer).  The measured life of a K=1024 ViT linear block is only
 // ~55 % K loop; the rest is launch + per-block set-up, the first chunk's DMA latency and the epilogue.  Here
 // 2 blocks per CU stay resident and walk the output tiles (ids b, b+G, b+2G, ... in the grouped order of tile_of);
 // the K chunks of consecutive tiles form ONE stream through the two LDS stages, so the first chunk of tile t+1 is
@@ -1462,29 +1282,6 @@ int launch_cfg(const pf_conv_params& p, hipStream_t st) {
   return p.relu_in ? launch_cfg2<T, BM, BN, WM, WN, true>(p, st) : launch_cfg2<T, BM, BN, WM, WN, false>(p, st);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool RELU_IN>
-int launch_ws2(const pf_conv_params& p, hipStream_t st) {
-  constexpr int smem = 2 * (BM + ((BN + 31) / 32) * 32) * 128;
-  static std::atomic<unsigned long long> attr_done{0};
-  auto kern = conv_igemm_ws_kernel<T, BM, BN, WM, WN, RELU_IN>;
-  ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
-  const long M = (long)p.B * p.OH * p.OW;
-  const long mt = (M + BM - 1) / BM, nt = (p.Cout + BN - 1) / BN;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(mt * nt)), dim3(64 * (WM * WN + 1)), smem, st, p);
-  return launch_status();
-}
-template <typename T, int BM, int BN, int WM, int WN>
-int launch_ws(const pf_conv_params& p, hipStream_t st) {
-  return p.relu_in ? launch_ws2<T, BM, BN, WM, WN, true>(p, st) : launch_ws2<T, BM, BN, WM, WN, false>(p, st);
-}
-// wave-specialised kernel: f32 layers whose K chunks stay inside one filter tap.  PF_F32_WS=0 (read per call) turns it off (A/B)
-template <typename T>
-bool use_ws(const pf_conv_params& p) {
-  if (sizeof(T) != 4 || p.shuffle > 1 || p.Cin % (8 * Elem<T>::VEC)) return false;
-  const char* e = getenv("PF_F32_WS");
-  return !(e && e[0] == '0');
-}
-
 int g_force_small = -1;   // PF_IGEMM_SMALL=1 forces the 4-wave kernel everywhere (A/B measurements)
 
 // Tile selection for the generic implicit-GEMM kernels: a wave-quantisation-aware cost model.
@@ -1525,11 +1322,13 @@ int dispatch(const pf_conv_params& p, hipStream_t st) {
     }
   }
   if constexpr (sizeof(T) == 2) {
-    // experimental persistent GEMM (see gemm_persist_kernel): opt-in only until it is validated and tuned on hardware.
-    // PF_GEMM_PERSIST (read per call): 1 = pick the shape by the makespan model below, or force "BMxBN" by its code
-    // 128128 / 12896 / 12864 / 144128 / 14464.
+    // persistent GEMM (see gemm_persist_kernel; validated by tests/test_persistent_gemm_gpu.py).
+    // PF_GEMM_PERSIST (read per call): 0 = off, 1 = every eligible layer with the shape picked by the makespan model below,
+    // or force "BMxBN" by its code 128128 / 12896 / 12864 / 144128 / 14464.
     const char* pe = getenv("PF_GEMM_PERSIST");
-    const int persist = pe ? atoi(pe) : 0;
+    // default: on for the wide linears (Cout >= 2048: ViT qkv / fc1, +2 ... +16 % measured, profiles/r2_sweep_bf16*.log);
+    // the narrow ones (proj, fc2: 520 tiles on 512 resident blocks) measured +-2 % and keep the one-tile kernel
+    const int persist = pe ? atoi(pe) : (p.Cout >= 2048 ? 1 : 0);
     if (persist > 0 && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.shuffle <= 1 && p.Cin % 64 == 0 && p.Cin >= 128 &&
         p.Cout >= 64 && M >= 1024) {
       // static schedule: block b takes tiles b, b+G, ...; every CU runs `occ` blocks side by side, so the makespan is
@@ -1594,17 +1393,6 @@ static int best_cfg(const pf_conv_params& p, long M, int cout, double* cost_out)
 
 template <typename T>
 int launch_generic(const pf_conv_params& p, hipStream_t st, int cfg) {
-  if constexpr (sizeof(T) == 4) {
-    if (use_ws<T>(p)) {
-      switch (cfg) {
-        case 1: return launch_ws<T, 128, 128, 2, 2>(p, st);
-        case 2: return launch_ws<T, 128, 96, 2, 2>(p, st);
-        case 3: return launch_ws<T, 128, 64, 2, 2>(p, st);
-        case 6: return launch_ws<T, 64, 64, 2, 2>(p, st);
-        default: break;
-      }
-    }
-  }
   switch (cfg) {
     case 0: if constexpr (sizeof(T) == 2) return p.relu_in ? launch_big<true>(p, st) : launch_big<false>(p, st);
     case 1: return launch_cfg<T, 128, 128, 2, 2>(p, st);
@@ -1681,6 +1469,7 @@ int validate(const pf_conv_params* p) {
   else if (p->KH * p->KW > 16) e = "at most 16 filter taps";
   else if ((long)p->B * p->OH * p->OW <= 0) e = "empty output";
   else if ((long)p->B * p->OH * p->OW >= (1L << 31)) e = "too many output pixels";
+  else if (p->korder != 0 && (p->korder != 1 || p->dtype != PF_DTYPE_F32 || p->Cin % 32 || p->shuffle > 1)) e = "korder 1 needs f32, Cin % 32 == 0, no shuffle";
   if (e) { snprintf(g_err, sizeof(g_err), "pf_conv: %s", e); return PF_ERR_ARG; }
   return PF_OK;
 }

@@ -71,6 +71,42 @@ __global__ void resize_bilinear_kernel(const void* __restrict__ x, int x_ld, int
   }
 }
 
+// Upv1 concat buffer in ONE pass (guided_fusion_model.py:96-99: cat[feat_enc, up(cat[temp, guide])] ): up to three
+// bilinear (align_corners=True) resizes of different sources / source sizes into consecutive channel ranges of the same
+// NHWC output row, so a wave writes whole contiguous rows instead of three strided channel slices in three launches.
+struct ResizeSrc {
+  const void* x;
+  int ld, H, W, C;
+  float sh, sw;
+};
+template <typename T>
+__global__ void resize_concat_kernel(ResizeSrc s0, ResizeSrc s1, ResizeSrc s2, int nsrc, int B, void* __restrict__ y, int y_ld,
+                                     int OH, int OW) {
+  const int cv0 = s0.C >> 3, cv1 = s1.C >> 3, cv2 = nsrc > 2 ? (s2.C >> 3) : 0;
+  const int cv = cv0 + cv1 + cv2;
+  const long total = (long)B * OH * OW * cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int v = (int)(i % cv);
+    const long pix = i / cv;
+    const int ox = (int)(pix % OW);
+    const int oy = (int)((pix / OW) % OH);
+    const int b = (int)(pix / ((long)OW * OH));
+    const int vout = v;
+    const ResizeSrc& s = v < cv0 ? s0 : (v < cv0 + cv1 ? s1 : s2);
+    v -= v < cv0 ? 0 : (v < cv0 + cv1 ? cv0 : cv0 + cv1);
+    const Lerp ly = ac_coord(oy, s.sh, s.H), lx = ac_coord(ox, s.sw, s.W);
+    const long base = (long)b * s.H * s.W;
+    float v00[8], v01[8], v10[8], v11[8], o[8];
+    ld8x<T>(s.x, (base + (long)ly.i0 * s.W + lx.i0) * s.ld + v * 8, 0, v00);
+    ld8x<T>(s.x, (base + (long)ly.i0 * s.W + lx.i1) * s.ld + v * 8, 0, v01);
+    ld8x<T>(s.x, (base + (long)ly.i1 * s.W + lx.i0) * s.ld + v * 8, 0, v10);
+    ld8x<T>(s.x, (base + (long)ly.i1 * s.W + lx.i1) * s.ld + v * 8, 0, v11);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = ly.l0 * (lx.l0 * v00[e] + lx.l1 * v01[e]) + ly.l1 * (lx.l0 * v10[e] + lx.l1 * v11[e]);
+    st8x<T>(y, pix * y_ld + vout * 8, 0, o);
+  }
+}
+
 __global__ void crop_resize_planar_kernel(const float* __restrict__ img, int C, int H, int W, const int* __restrict__ boxes, int P,
                                           float* __restrict__ out, int oh, int ow) {
   const long total = (long)P * C * oh * ow;
@@ -408,6 +444,21 @@ extern "C" int pf_resize_bilinear(const void* x, int x_ld, int B, int H, int W, 
   if (!x || !y || C % 8 || x_ld % 8 || y_ld % 8 || (add && add_ld % 8)) return PF_ERR_ARG;
   const long total = (long)B * OH * OW * (C / 8);
   LAUNCH_T(resize_bilinear_kernel, total, x, x_ld, B, H, W, C, y, y_ld, OH, OW, add, add_ld, in_f32, out_f32, ac_scale(H, OH), ac_scale(W, OW));
+  return ok();
+}
+
+extern "C" int pf_resize_concat(const void* const* xs, const int* lds, const int* Hs, const int* Ws, const int* Cs, int nsrc, int B,
+                                void* y, int y_ld, int OH, int OW, int dtype, void* stream) {
+  if (!xs || !lds || !Hs || !Ws || !Cs || !y || nsrc < 2 || nsrc > 3 || y_ld % 8) return PF_ERR_ARG;
+  ResizeSrc s[3] = {};
+  long cv = 0;
+  for (int i = 0; i < nsrc; ++i) {
+    if (!xs[i] || Cs[i] % 8 || lds[i] % 8) return PF_ERR_ARG;
+    s[i] = ResizeSrc{xs[i], lds[i], Hs[i], Ws[i], Cs[i], ac_scale(Hs[i], OH), ac_scale(Ws[i], OW)};
+    cv += Cs[i] / 8;
+  }
+  const long total = (long)B * OH * OW * cv;
+  LAUNCH_T(resize_concat_kernel, total, s[0], s[1], s[2], nsrc, B, y, y_ld, OH, OW);
   return ok();
 }
 

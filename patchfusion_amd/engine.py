@@ -451,10 +451,12 @@ class FusionNet:
             else:
                 cp = ch[i - 1]
                 u = u5 if i == 5 else ops.empty((B, h, w, c + 2 * cp), dt, dev)
+                # Upv1 concat buffer [enc resized to the DPT grid | up(temp) | up(guide)] in ONE launch (whole rows of u);
+                # at the last level enc already sits in u5[..., :32] (the inc conv wrote it there)
                 if i < 5:
-                    ops.resize(enc[i], u[..., :c])                   # encoder map resized to the DPT grid
-                ops.resize(temp, u[..., c:c + cp])
-                ops.resize(guide[i - 1], u[..., c + cp:])
+                    ops.resize_concat([enc[i], temp, guide[i - 1]], u)
+                else:
+                    ops.resize_concat([temp, guide[i - 1]], u[..., c:])
                 c0, c1 = self.upc[i - 1]
                 t = ops.empty((B, h, w, c0.cout), dt, dev)
                 ops.conv(u, c0, t, pad=1, act="relu")

@@ -106,6 +106,7 @@ class HipOps:
         assert pw.w.dtype == x4.dtype, "weights must be packed in the activation dtype"
         p.out_f32 = int(y4.dtype == torch.float32 and x4.dtype != torch.float32)
         p.shuffle = s
+        p.korder = pw.korder
         for t in (x4, y4, pw.w, res, res2):
             _p(t)
         if _timed is not None:
@@ -190,6 +191,20 @@ class HipOps:
             assert add.dtype == y4.dtype
         check(_L.pf_resize_bilinear(_p(x4), _ld(x4), B, H, W, Cc, _p(y4), _ld(y4), OH, OW, _p(add), _ld(add) if add is not None else 0,
                                     in_f32, out_f32, code, _stream()), "pf_resize_bilinear")
+
+    @staticmethod
+    def resize_concat(xs, y):
+        """y[..., c0:c0+C_i] = bilinear(xs[i]) for 2 or 3 NHWC sources of the compute dtype (one launch, whole rows of y)"""
+        n = len(xs)
+        y4 = _as4(y)
+        B, OH, OW, Ct = y4.shape
+        assert 2 <= n <= 3 and sum(x.shape[-1] for x in xs) <= Ct and all(x.dtype == y4.dtype and x.shape[0] == B for x in xs)
+        ptrs = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+        arr = lambda v: (C.c_int * n)(*v)
+        for t in list(xs) + [y4]:
+            _p(t)
+        check(_L.pf_resize_concat(ptrs, arr([_ld(x) for x in xs]), arr([x.shape[1] for x in xs]), arr([x.shape[2] for x in xs]),
+                                  arr([x.shape[3] for x in xs]), n, B, _p(y4), _ld(y4), OH, OW, _dt(y4), _stream()), "pf_resize_concat")
 
     @staticmethod
     def crop_resize(img, boxes, out):

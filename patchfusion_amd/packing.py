@@ -30,6 +30,7 @@ class PackedConv:
     cout: int                       # channels stored (multiple of 4); GEMM N
     cout_real: int
     shuffle: int = 1                # s for ConvTranspose2d(kernel=stride=s)
+    korder: int = 0                 # K order of `w`: 0 = (ky, kx, c) tap-major; 1 = (c / 32, ky, kx, c % 32) chunk-major
 
     def to(self, device):
         self.w = self.w.to(device)
@@ -71,7 +72,14 @@ def pack_conv(weight, bias=None, *, dtype, cin_map=None, cin_total=None, scale=N
     K = KH * KW * cin_total
     Kpad = round_up(K, k_chunk(dtype))
     wp = torch.zeros(rows, Kpad)
-    wp[:, :K] = wk.reshape(rows, K)
+    # float32 k x k layers whose channels fill whole 128-byte chunks: CHUNK-MAJOR K order -- the kernel then walks all
+    # KH*KW taps of one 32-channel chunk back to back, so the 9 re-reads of an input pixel hit L2 (the f32 activation
+    # tensors are GBs: with the tap-major order every tap pass streams them from HBM again, 64 GB per dominant launch)
+    korder = 1 if (dtype == torch.float32 and KH * KW > 1 and cin_total % 32 == 0) else 0
+    if korder:
+        wp[:, :K] = wk.reshape(rows, KH * KW, cin_total // 32, 32).permute(0, 2, 1, 3).reshape(rows, K)
+    else:
+        wp[:, :K] = wk.reshape(rows, K)
     bp = None
     if b is not None:
         bp = torch.zeros(rows)
@@ -80,7 +88,7 @@ def pack_conv(weight, bias=None, *, dtype, cin_map=None, cin_total=None, scale=N
     if scale is not None:
         sp = torch.zeros(rows)
         sp[:cout] = scale.detach().float().cpu()
-    return PackedConv(wp.to(dtype).contiguous(), bp, sp, KH, KW, cin_total, cout_store, cout)
+    return PackedConv(wp.to(dtype).contiguous(), bp, sp, KH, KW, cin_total, cout_store, cout, korder=korder)
 
 
 def pack_conv_transpose(weight, bias, *, dtype):
@@ -105,8 +113,10 @@ def unpack_conv(pc: PackedConv):
     buffer's channel axis (tests/fake_ops.py uses it to drive F.conv2d with the PACKED weights, so the
     packing itself is covered by the CPU wiring tests)."""
     K = pc.KH * pc.KW * pc.cin
-    w = pc.w.float()[:pc.cout, :K].reshape(pc.cout, pc.KH, pc.KW, pc.cin).permute(0, 3, 1, 2).contiguous()
-    return w
+    w = pc.w.float()[:pc.cout, :K]
+    if pc.korder:
+        w = w.reshape(pc.cout, pc.cin // 32, pc.KH * pc.KW, 32).permute(0, 2, 1, 3)
+    return w.reshape(pc.cout, pc.KH, pc.KW, pc.cin).permute(0, 3, 1, 2).contiguous()
 
 
 def vit_pos_embed(pos_embed, th, tw):

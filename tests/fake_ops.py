@@ -157,6 +157,13 @@ class FakeOps:
         y4[..., :C] = v.to(y4.dtype)
 
     @staticmethod
+    def resize_concat(xs, y):
+        c0 = 0
+        for x in xs:
+            FakeOps.resize(x, y[..., c0:c0 + x.shape[-1]])
+            c0 += x.shape[-1]
+
+    @staticmethod
     def crop_resize(img, boxes, out):
         P, _, oh, ow = out.shape
         for p, (x0, y0, x1, y1) in enumerate(boxes.tolist()):

@@ -314,6 +314,16 @@ def resize_ops(dt):
             o.resize(x, y2, add=add)
             res.append((buf, y2))
         errs += [_err(a, c) for a, c in zip(res[0], res[1])]
+    # the Upv1 concat buffer in one launch: 3 sources of different sizes / 2 sources into a channel slice of a wider buffer
+    e0, t0, g0 = _rand((2, 49, 64, 64), dt, 31), _rand((2, 28, 37, 128), dt, 32), _rand((2, 28, 37, 128), dt, 33)
+    res = []
+    for o in (hip(), ref_ops):
+        u = torch.zeros((2, 56, 74, 320), dtype=dt, device=DEV)
+        o.resize_concat([e0, t0, g0], u)
+        u5 = torch.zeros((2, 56, 74, 32 + 256), dtype=dt, device=DEV)
+        o.resize_concat([t0, g0], u5[..., 32:])
+        res.append((u, u5))
+    errs += [_err(a, c) for a, c in zip(res[0], res[1])]
     # f32 source -> dt destination (embedding upsample into the CLB buffer) and planar helpers
     img = torch.rand(3, 96, 130, generator=torch.Generator().manual_seed(5)).to(DEV)
     boxes = torch.tensor([[0, 0, 65, 48], [65, 48, 130, 96], [13, 7, 78, 55]], dtype=torch.int32, device=DEV)

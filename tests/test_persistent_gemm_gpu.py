@@ -1,21 +1,21 @@
-"""Opt-in checks of kernels that are NOT dispatched by default (skipped unless PF_TEST_EXPERIMENTAL=1).
+"""pytest -m gpu: the persistent bf16 GEMM (`gemm_persist_kernel`, patchfusion_amd/csrc/igemm.hip), which the dispatcher uses by
+default for the wide 1x1 / linear layers (Cout >= 2048: ViT qkv, fc1).
 
-  PF_TEST_EXPERIMENTAL=1 python -m pytest tests/test_experimental_gpu.py -m gpu -q
-
-PF_GEMM_PERSIST (read per call: 1 = shape chosen by the makespan model, or a forced shape code 128128 / 12896 / 12864 /
-144128 / 14464 = BMxBN) routes every bf16 1x1 / linear layer with Cin % 64 == 0, Cin >= 128, Cout >= 64 and >= 1024
-rows to the persistent GEMM (`gemm_persist_kernel`, patchfusion_amd/csrc/igemm.hip).
+PF_GEMM_PERSIST (read per call: 0 = off, 1 = every eligible layer with the shape chosen by the makespan model, or a forced
+shape code 128128 / 12896 / 12864 / 144128 / 14464 = BMxBN) routes every bf16 1x1 / linear layer with Cin % 64 == 0,
+Cin >= 128, Cout >= 64 and >= 1024 rows to it.  All six modes x all cases below passed on hardware in round 2
+(gpurun_out/r2_experimental.log: 48 passed); the default run keeps three modes (PF_TEST_ALL_PERSIST_SHAPES=1 runs all six).
 """
 import os
 
 import pytest
 import torch
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("PF_TEST_EXPERIMENTAL") != "1", reason="experimental kernels are opt-in")]
+pytestmark = pytest.mark.gpu
+MODES = ["1", "128128", "12896", "12864", "144128", "14464"] if os.environ.get("PF_TEST_ALL_PERSIST_SHAPES") == "1" else ["1", "12864", "144128"]
 
 
-@pytest.fixture(params=["1", "128128", "12896", "12864", "144128", "14464"])
+@pytest.fixture(params=MODES)
 def persist_mode(request):
     old = os.environ.get("PF_GEMM_PERSIST")
     os.environ["PF_GEMM_PERSIST"] = request.param

@@ -92,6 +92,12 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 // at once form a roughly square patch of the output (8 pixel tiles x 8 channel tiles) whose A and W panels fit that
 // XCD's 4 MiB L2 together, instead of 2 pixel tiles x every channel tile (the whole weight matrix streaming through L2
 // once per pair of pixel tiles).
+// measured on the ViT-L linears (gpurun_out/r2c9_sweep_persist_*.log): qkv 500 -> 609, fc1 631 -> 652 TF/s with the 256x128
+// eight-wave tile; 256x256 (one block per CU, 2 rounds of 396 / 3 rounds of 528 tiles) loses to it: never picked (0), forced only
+#ifndef PF_PERSIST_EFF_256128
+#define PF_PERSIST_EFF_256128 1.25f
+#define PF_PERSIST_EFF_256256 0.0f
+#endif
 #ifndef PF_IGEMM_GROUP_M
 #define PF_IGEMM_GROUP_M 8
 #endif
@@ -485,17 +491,23 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_persist_kernel(const pf_con
     for (int fn = 0; fn < FN; ++fn)
 #pragma unroll
       for (int fm = 0; fm < FM; ++fm) acc[fn][fm] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // per-channel epilogue constants: before the K loop when they are few (their latency hides behind it), after it for
+    // the wide tiles (2 x FN float4 registers would not fit next to 128 accumulator registers)
+    constexpr bool kPreload = FN <= 4 && FM * FN <= 16;
     float4 bias_r[FN], scale_r[FN];
+    auto load_epi = [&]() {
 #pragma unroll
-    for (int fn = 0; fn < FN; ++fn) {
-      const int n = n0 + wn * WTN + fn * 16 + fg * 4;
-      bias_r[fn] = make_float4(0.f, 0.f, 0.f, 0.f);
-      scale_r[fn] = make_float4(1.f, 1.f, 1.f, 1.f);
-      if (n < p.Cout) {
-        if (p.bias) bias_r[fn] = *reinterpret_cast<const float4*>(p.bias + n);
-        if (p.scale) scale_r[fn] = *reinterpret_cast<const float4*>(p.scale + n);
+      for (int fn = 0; fn < FN; ++fn) {
+        const int n = n0 + wn * WTN + fn * 16 + fg * 4;
+        bias_r[fn] = make_float4(0.f, 0.f, 0.f, 0.f);
+        scale_r[fn] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (n < p.Cout) {
+          if (p.bias) bias_r[fn] = *reinterpret_cast<const float4*>(p.bias + n);
+          if (p.scale) scale_r[fn] = *reinterpret_cast<const float4*>(p.scale + n);
+        }
       }
-    }
+    };
+    if constexpr (kPreload) load_epi();
     for (int kc = 0; kc < nk; ++kc, ++c) {
       if (issued == c + 1 && issued < total) issue_next();           // keep one chunk ahead (skipped when two ahead)
       const char* As = smem + (c & 1) * STAGE;
@@ -518,6 +530,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_persist_kernel(const pf_con
     }
     // tile finished: its last stage is free -> put the NEXT tile's second chunk in flight behind the epilogue
     if (issued == c + 1 && issued < total) issue_next();
+    if constexpr (!kPreload) load_epi();
     // ---- epilogue (same order as conv_igemm_kernel: bias -> act -> scale -> residual(s) -> store) ----
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm) {
@@ -1334,19 +1347,24 @@ int dispatch(const pf_conv_params& p, hipStream_t st) {
       // static schedule: block b takes tiles b, b+G, ...; every CU runs `occ` blocks side by side, so the makespan is
       // ceil(tiles / (256 occ)) tiles per block at occ tiles per CU-time (8296 x 1024 outputs: 520 tiles of 128x128
       // on 512 resident blocks are two rounds; 464 tiles of 144x128 are one)
-      struct Cand { int code, bm, bn, occ; };
-      const Cand cand[5] = {{128128, 128, 128, PersistCfg<128, 128, 2, 2>::occ}, {12896, 128, 96, PersistCfg<128, 96, 2, 2>::occ},
-                            {12864, 128, 64, PersistCfg<128, 64, 2, 2>::occ}, {144128, 144, 128, PersistCfg<144, 128, 3, 2>::occ},
-                            {14464, 144, 64, PersistCfg<144, 64, 3, 2>::occ}};
+      // eff: relative matrix-pipe efficiency of a tile shape once resident (the 128-row tiles are bound by the texture-address
+      // path: 32 KB of LDS-DMA per 512 MFMA cycles; a 256x256 tile moves half the bytes per MFMA) -- calibrated on the ViT-L linears
+      struct Cand { int code, bm, bn, occ; float eff; };
+      const Cand cand[7] = {{128128, 128, 128, PersistCfg<128, 128, 2, 2>::occ, 1.f}, {12896, 128, 96, PersistCfg<128, 96, 2, 2>::occ, 1.f},
+                            {12864, 128, 64, PersistCfg<128, 64, 2, 2>::occ, 1.f}, {144128, 144, 128, PersistCfg<144, 128, 3, 2>::occ, 1.f},
+                            {14464, 144, 64, PersistCfg<144, 64, 3, 2>::occ, 1.f},
+                            {256128, 256, 128, PersistCfg<256, 128, 4, 2>::occ, PF_PERSIST_EFF_256128},
+                            {256256, 256, 256, PersistCfg<256, 256, 4, 2>::occ, PF_PERSIST_EFF_256256}};
       int code = persist;
       bool known = false;
-      for (int i = 0; i < 5; ++i) known = known || cand[i].code == code;
+      for (int i = 0; i < 7; ++i) known = known || cand[i].code == code;
       if (!known) {
         double best = 1e300;
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < 7; ++i) {
           const long tiles = ((M + cand[i].bm - 1) / cand[i].bm) * ((p.Cout + cand[i].bn - 1) / cand[i].bn);
           const long rounds = (tiles + 256L * cand[i].occ - 1) / (256L * cand[i].occ);
-          const double cost = (double)rounds * cand[i].occ * cand[i].bm * cand[i].bn;
+          if (cand[i].eff <= 0.f) continue;
+          const double cost = (double)rounds * cand[i].occ * cand[i].bm * cand[i].bn / cand[i].eff;
           if (cost < best) { best = cost; code = cand[i].code; }
         }
       }
@@ -1357,6 +1375,8 @@ int dispatch(const pf_conv_params& p, hipStream_t st) {
       PF_PERSIST_CASE(12864, 128, 64, 2, 2)
       PF_PERSIST_CASE(144128, 144, 128, 3, 2)
       PF_PERSIST_CASE(14464, 144, 64, 3, 2)
+      PF_PERSIST_CASE(256128, 256, 128, 4, 2)
+      PF_PERSIST_CASE(256256, 256, 256, 4, 2)
 #undef PF_PERSIST_CASE
     }
   }

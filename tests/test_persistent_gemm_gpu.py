@@ -2,9 +2,10 @@
 default for the wide 1x1 / linear layers (Cout >= 2048: ViT qkv, fc1).
 
 PF_GEMM_PERSIST (read per call: 0 = off, 1 = every eligible layer with the shape chosen by the makespan model, or a forced
-shape code 128128 / 12896 / 12864 / 144128 / 14464 = BMxBN) routes every bf16 1x1 / linear layer with Cin % 64 == 0,
-Cin >= 128, Cout >= 64 and >= 1024 rows to it.  All six modes x all cases below passed on hardware in round 2
-(gpurun_out/r2_experimental.log: 48 passed); the default run keeps three modes (PF_TEST_ALL_PERSIST_SHAPES=1 runs all six).
+shape code 128128 / 12896 / 12864 / 144128 / 14464 / 256128 / 256256 = BMxBN) routes every bf16 1x1 / linear layer with Cin % 64 == 0,
+Cin >= 128, Cout >= 64 and >= 1024 rows to it.  Every shape mode x every case below passed on hardware in round 2
+(gpurun_out/r2_experimental.log: 48 passed; r2c9_persist_tests.log: 24 passed incl. the 256-row shapes); the default run
+keeps the model-chosen shape and the 256x128 eight-wave shape (PF_TEST_ALL_PERSIST_SHAPES=1 runs all eight modes).
 """
 import os
 
@@ -12,7 +13,8 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-MODES = ["1", "128128", "12896", "12864", "144128", "14464"] if os.environ.get("PF_TEST_ALL_PERSIST_SHAPES") == "1" else ["1", "12864", "144128"]
+ALL_MODES = ["1", "128128", "12896", "12864", "144128", "14464", "256128", "256256"]
+MODES = ALL_MODES if os.environ.get("PF_TEST_ALL_PERSIST_SHAPES") == "1" else ["1", "256128"]
 
 
 @pytest.fixture(params=MODES)

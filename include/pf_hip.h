@@ -188,6 +188,12 @@ int pf_depth_to_u16(const float* depth, long n, float scale, uint16_t* out, void
 int pf_depth_metrics(const float* gt, int H, int W, const float* pred, int ph, int pw, const float* edges, float min_depth,
                      float max_depth, int crop_y0, int crop_y1, int crop_x0, int crop_x1, double* out13, void* stream);
 
+/* SILogLoss forward value (estimator/models/losses.py:15-62), the loss of PatchFusion.forward(mode='train') (patchfusion.py:395):
+ * pred / target float32 [n] of equal size; ws3 = 3 doubles of device scratch; *loss (device float) = 10*sqrt(var(g) + beta*mean(g)^2)
+ * over min_depth < target < max_depth, g = log(pred+1e-7) - log(target+1e-7); 0 when <= 1 valid element. */
+int pf_silog_loss(const float* pred, const float* target, long n, float min_depth, float max_depth, float beta, double* ws3,
+                  float* loss, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

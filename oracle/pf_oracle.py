@@ -399,6 +399,17 @@ def fusion_forward(sd, cfg, fine_depth, crops, coarse_feats, fine_feats, bbox, c
     return bins_head(sd, "", fused[0], fused[1:-1], last, rel_cond, cfg["coarse_branch"], None)
 
 
+def silog_loss(pred, target, min_depth, max_depth, beta=0.15):
+    """SILogLoss.forward -- estimator/models/losses.py:23-46 (no additional_mask)."""
+    if pred.shape[-2:] != target.shape[-2:]:
+        pred = up(pred, target.shape[-2:])
+    mask = torch.logical_and(target > min_depth, target < max_depth)
+    if torch.sum(mask) <= 1:
+        return pred * 0.0
+    g = torch.log(pred[mask] + 1e-7) - torch.log(target[mask] + 1e-7)
+    return 10 * torch.sqrt(torch.var(g) + beta * torch.pow(torch.mean(g), 2))
+
+
 # ------------------------------------------------------------------------------------------
 # Tiling / stitching
 # ------------------------------------------------------------------------------------------
@@ -539,6 +550,22 @@ class Oracle:
                 avg.update(pred, count)
                 idx += 1
         return avg
+
+    @torch.no_grad()
+    def train_forward(self, image_lr, crops_image_hr, crop_depths, bboxs):
+        """PatchFusion.forward(mode='train') -- patchfusion.py:372-399: coarse branch on the batch of low-resolution images, fine
+        branch on one crop per image, coarse_postprocess_train (:227-237: roi_align with batch index i), fusion_forward,
+        SILogLoss (losses.py:15-62).  Forward value only.  Returns (sig_loss, depth_prediction [B,1,h,w])."""
+        cfg, sd = self.cfg, self.sd
+        H, W = cfg["image_raw_shape"]
+        fac = torch.tensor([1 / W * self.ps[1], 1 / H * self.ps[0], 1 / W * self.ps[1], 1 / H * self.ps[0]], device=bboxs.device).unsqueeze(0)
+        bf = torch.cat((torch.arange(bboxs.shape[0], device=bboxs.device).unsqueeze(-1), bboxs * fac), dim=-1)
+        cdepth, cfeats = any_branch_forward(sd, "coarse_branch.", image_lr, cfg["coarse_branch"], self.providers[0])
+        fdepth, ffeats = any_branch_forward(sd, "fine_branch.", crops_image_hr, cfg["fine_branch"], self.providers[1])
+        feats_roi = [tp.roi_align(f, bf, f.shape[-2:], f.shape[-2] / self.ps[0], aligned=True) for f in cfeats]
+        depth_roi = tp.roi_align(cdepth, bf, cdepth.shape[-2:], cdepth.shape[-2] / self.ps[0], aligned=True)
+        pred = fusion_forward(sd, cfg, fdepth, crops_image_hr, cfeats, ffeats, bf, depth_roi, feats_roi, g2l_cache=None)
+        return silog_loss(pred, crop_depths, cfg["min_depth"], cfg["max_depth"]), pred
 
     @torch.no_grad()
     def infer(self, image_lr, image_hr, cai_mode="m1", process_num=4, tile_cfg=None, taps=None):

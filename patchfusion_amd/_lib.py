@@ -58,6 +58,7 @@ SIGNATURES = {
     "pf_percentiles_f32": [vp, cl, cf, ci, C.c_double, C.c_double, vp, vp, vp],
     "pf_colorize_f32": [vp, cl, vp, vp, ci, cf, ci, C.c_uint32, vp, vp],
     "pf_depth_to_u16": [vp, cl, cf, vp, vp],
+    "pf_silog_loss": [vp, vp, cl, cf, cf, cf, vp, vp, vp],
     "pf_depth_metrics": [vp, ci, ci, vp, ci, ci, vp, cf, cf, ci, ci, ci, ci, vp, vp],
 }
 NON_STATUS = ("pf_last_error", "pf_version", "pf_percentile_workspace_bytes")   # entry points that do not return a status

@@ -390,6 +390,46 @@ __global__ __launch_bounds__(256) void depth_metrics_kernel(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// SILogLoss forward (estimator/models/losses.py:15-62, the loss of PatchFusion.forward(mode='train'), patchfusion.py:395):
+// mask = min < target < max; g = log(input + 1e-7) - log(target + 1e-7) in float32 like torch; the masked count, sum and
+// sum of squares are accumulated in double; loss = 10 * sqrt(var_unbiased(g) + beta * mean(g)^2); 0 when <= 1 valid pixel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void silog_sums_kernel(const float* __restrict__ pred, const float* __restrict__ target, long n,
+                                                         float lo, float hi, double* __restrict__ out3) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float t = target[i];
+    if (!(t > lo && t < hi)) continue;
+    const float g = logf(pred[i] + 1e-7f) - logf(t + 1e-7f);
+    s0 += 1.0;
+    s1 += (double)g;
+    s2 += (double)g * (double)g;
+  }
+  __shared__ double red[3][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double v[3] = {s0, s1, s2};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
+    if (lane == 0) red[k][wave] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const double r = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+    if (r != 0.0) atomicAdd(&out3[threadIdx.x], r);
+  }
+}
+__global__ void silog_finish_kernel(const double* __restrict__ s, float beta, float* __restrict__ loss) {
+  if (threadIdx.x != 0) return;
+  const double n = s[0];
+  if (n <= 1.0) { *loss = 0.f; return; }
+  const double mean = s[1] / n;
+  const double var = fmax((s[2] - s[1] * s[1] / n) / (n - 1.0), 0.0);
+  *loss = (float)(10.0 * sqrt(var + (double)beta * mean * mean));
+}
+
 __global__ void zero_f64_kernel(double* p, int n) {
   if ((int)threadIdx.x < n) p[threadIdx.x] = 0.0;
 }
@@ -445,5 +485,14 @@ extern "C" int pf_depth_metrics(const float* gt, int H, int W, const float* pred
   hipLaunchKernelGGL(zero_f64_kernel, dim3(1), dim3(64), 0, ST(stream), out13, MET_N);
   hipLaunchKernelGGL(depth_metrics_kernel, dim3(grid_for((long)H * W, 256)), dim3(256), 0, ST(stream), gt, H, W, pred, ph, pw, edges,
                      min_depth, max_depth, crop_y0, crop_y1, crop_x0, crop_x1, out13);
+  return ok();
+}
+
+extern "C" int pf_silog_loss(const float* pred, const float* target, long n, float min_depth, float max_depth, float beta, double* ws3,
+                             float* loss, void* stream) {
+  if (!pred || !target || !ws3 || !loss || n <= 0) return PF_ERR_ARG;
+  hipLaunchKernelGGL(zero_f64_kernel, dim3(1), dim3(64), 0, ST(stream), ws3, 3);
+  hipLaunchKernelGGL(silog_sums_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ST(stream), pred, target, n, min_depth, max_depth, ws3);
+  hipLaunchKernelGGL(silog_finish_kernel, dim3(1), dim3(64), 0, ST(stream), ws3, beta, loss);
   return ok();
 }

@@ -348,6 +348,16 @@ class HipOps:
         return out
 
     @staticmethod
+    def silog_loss(pred, target, min_depth, max_depth, beta=0.15):
+        """SILogLoss forward (losses.py:15-62): pred, target float32 of equal shape -> device float32 scalar tensor"""
+        assert pred.dtype == target.dtype == torch.float32 and pred.shape == target.shape and pred.is_contiguous() and target.is_contiguous()
+        ws = torch.empty(3, dtype=torch.float64, device=pred.device)
+        loss = torch.empty((), dtype=torch.float32, device=pred.device)
+        check(_L.pf_silog_loss(_p(pred), _p(target), pred.numel(), float(min_depth), float(max_depth), float(beta), _p(ws), _p(loss),
+                               _stream()), "pf_silog_loss")
+        return loss
+
+    @staticmethod
     def depth_metrics(gt, pred, edges, min_depth, max_depth, crop, out13):
         """gt [H,W], pred [h,w] float32, edges [H,W] float32 or None, crop = (y0, y1, x0, x1) -> out13 (device float64 [13])."""
         assert gt.dtype == torch.float32 and pred.dtype == torch.float32 and gt.dim() == 2 and pred.dim() == 2

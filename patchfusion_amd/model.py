@@ -11,7 +11,8 @@ What is mirrored:
   * ``tile_cfg``, ``resizer``, ``patch_process_shape``, ``coarse_forward``, ``fine_forward``, ``infer_forward``
   * errors: AssertionError for divisibility / batch-1, NotImplementedError for unknown branch types,
     ValueError for bin_centers_type -- same exception types as the reference.
-Out of scope (north star is inference): ``mode='train'`` raises NotImplementedError.
+``mode='train'`` computes the reference's training-mode FORWARD (loss value, patchfusion.py:372-399) without autograd: the
+engine has no backward kernels (north star is inference).
 
 Multi-GPU: two axes, like the reference leaves them.
   * image-level data parallelism (tools/test.py:218-239: DDP + DistributedSampler, every rank holds a
@@ -450,12 +451,48 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
             avg = a2
         return avg
 
+    # ------------------------------------------------------------------ training-mode forward (forward VALUE only)
+    @torch.no_grad()
+    def train_forward(self, image_lr, crops_image_hr, crop_depths, bboxs):
+        """``forward(mode='train')`` of the reference, patchfusion.py:372-399: B images, one random crop
+        each -> coarse branch on ``image_lr`` [B,3,h,w], fine branch on ``crops_image_hr`` [B,3,h,w],
+        ``coarse_postprocess_train`` (roi_align of image i's coarse maps with box i, :227-237), ``fusion_forward``, SILogLoss
+        against ``crop_depths`` [B,1,h,w].  Returns ``(loss_dict, {'rgb','depth_pred','depth_gt'})`` like the reference.
+        FORWARD VALUE ONLY: the engine has no backward kernels, the returned tensors carry no autograd graph (use it for
+        validation loss / to check a training pipeline's data path; optimisation steps need the reference's PyTorch modules)."""
+        nets = self._ensure_engine()
+        ops, dev = self.ops, self._device
+        B = image_lr.shape[0]
+        assert crops_image_hr.shape[0] == B and bboxs.shape[0] == B
+        H, W = self.tile_cfg['image_raw_shape']
+        ps = self.patch_process_shape
+        # bboxs * bboxs_feat_factor in float32 exactly like patchfusion.py:373-380, batch index i = image i
+        fac = torch.tensor([1 / W * ps[1], 1 / H * ps[0], 1 / W * ps[1], 1 / H * ps[0]], device=bboxs.device).unsqueeze(0)
+        bf = bboxs * fac
+        rois = torch.cat((torch.arange(B, device=bboxs.device).unsqueeze(-1), bf), dim=-1).to(device=dev, dtype=torch.float32).contiguous()
+        cdepth, cfeats = nets["coarse"].forward(ops, image_lr.contiguous().float())
+        g2l = nets["g2l"].forward(ops, cfeats)            # per image here (batch B): the coarse maps differ per sample
+        crops = crops_image_hr.contiguous().float()
+        fdepth, ffeats = nets["fine"].forward(ops, crops)
+        d = nets["fusion"].forward(ops, crops, rois, fdepth, ffeats, cdepth.view(B, 1, *cdepth.shape[1:]), cfeats, g2l)
+        depth_prediction = d.unsqueeze(1)
+        loss_dict = {}
+        if crop_depths is not None:
+            gt = crop_depths.to(device=dev, dtype=torch.float32)
+            pred = depth_prediction
+            if tuple(gt.shape[-2:]) != tuple(pred.shape[-2:]):      # losses.py:27-28
+                pred = F.interpolate(pred, tuple(gt.shape[-2:]), mode='bilinear', align_corners=True)
+            loss_dict['sig_loss'] = ops.silog_loss(pred.contiguous(), gt.contiguous(), self.min_depth, self.max_depth,
+                                                   float(self.config.sigloss.get('beta', 0.15)) if isinstance(self.config.get('sigloss'), dict) else 0.15)
+            loss_dict['total_loss'] = loss_dict['sig_loss']
+        return loss_dict, {'rgb': crops_image_hr, 'depth_pred': depth_prediction, 'depth_gt': crop_depths}
+
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
     def forward(self, mode, image_lr, image_hr, depth_gt=None, crops_image_hr=None, crop_depths=None, bboxs=None,
                 tile_cfg=None, cai_mode='m1', process_num=4):
         if mode == 'train':
-            raise NotImplementedError("training forward is out of scope of the MI355X inference engine")
+            return self.train_forward(image_lr, crops_image_hr, crop_depths, bboxs)
         if tile_cfg is None:
             tile_cfg = self.tile_cfg
         else:

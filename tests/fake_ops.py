@@ -308,6 +308,14 @@ class FakeOps:
         return out
 
     @staticmethod
+    def silog_loss(pred, target, min_depth, max_depth, beta=0.15):
+        mask = torch.logical_and(target > min_depth, target < max_depth)
+        if int(mask.sum()) <= 1:
+            return torch.zeros((), dtype=torch.float32, device=pred.device)
+        g = torch.log(pred[mask] + 1e-7) - torch.log(target[mask] + 1e-7)
+        return 10 * torch.sqrt(torch.var(g) + beta * torch.pow(torch.mean(g), 2))
+
+    @staticmethod
     def depth_metrics(gt, pred, edges, min_depth, max_depth, crop, out13):
         import numpy as np
         from oracle import io_oracle

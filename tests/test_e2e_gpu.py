@@ -206,3 +206,20 @@ def test_zoe_midas_core_geometry_r_mode_vs_oracle():
         assert err <= tol, (dtype, err)
         del m
         torch.cuda.empty_cache()
+
+
+def test_train_mode_forward_vs_oracle():
+    """`forward(mode='train')` (patchfusion.py:372-399) on the HIP engine: forward value of the training step
+    (batch of 2 images, one crop each, roi_align with per-sample batch index, fusion, SILogLoss kernel) vs the oracle, which is
+    pinned to the reference's own train forward (tests/test_train_forward_cpu.py)."""
+    from tests.test_train_forward_cpu import train_batch
+    cfg, sd, m, _ = build(*TINY, "fp32")
+    image_lr, crops, bboxs, gt = train_batch()
+    loss_dict, aux = m(mode="train", image_lr=image_lr.cuda(), image_hr=None, crops_image_hr=crops.cuda(), crop_depths=gt.cuda(),
+                       bboxs=bboxs.cuda())
+    ref_loss, ref_pred = pf_oracle.Oracle(cfg, sd).train_forward(image_lr, crops, gt, bboxs)
+    assert float((aux["depth_pred"].cpu() - ref_pred).abs().max()) < 2e-4
+    assert abs(float(loss_dict["total_loss"]) - float(ref_loss)) < 1e-3 * max(1.0, abs(float(ref_loss)))
+    # degenerate mask: <= 1 valid pixel -> 0 (losses.py:38-40)
+    z = m.ops.silog_loss(aux["depth_pred"].contiguous(), torch.zeros_like(aux["depth_pred"]), 1e-3, 80)
+    assert float(z) == 0.0

@@ -92,11 +92,14 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 // at once form a roughly square patch of the output (8 pixel tiles x 8 channel tiles) whose A and W panels fit that
 // XCD's 4 MiB L2 together, instead of 2 pixel tiles x every channel tile (the whole weight matrix streaming through L2
 // once per pair of pixel tiles).
-// measured on the ViT-L linears (gpurun_out/r2c9_sweep_persist_*.log): qkv 500 -> 609, fc1 631 -> 652 TF/s with the 256x128
-// eight-wave tile; 256x256 (one block per CU, 2 rounds of 396 / 3 rounds of 528 tiles) loses to it: never picked (0), forced only
+// measured on the ViT-L linears (profiles/r2_sweep_bf16_persist_shapes.log): qkv 500 -> 609, fc1 631 -> 652 TF/s with the
+// 256x128 eight-wave tile; a 256x256 tile (one block per CU: 2 rounds of 396 / 3 rounds of 528 tiles, and 64 B/lane of
+// epilogue spill at 256 registers) measured 576 / 558 and was dropped
 #ifndef PF_PERSIST_EFF_256128
 #define PF_PERSIST_EFF_256128 1.25f
-#define PF_PERSIST_EFF_256256 0.0f
+#endif
+#ifndef PF_F32_EFF_256      // relative efficiency of the eight-wave 256x256 f32 tile in the cost model; 0 = forced (PF_IGEMM_CFG=7) only
+#define PF_F32_EFF_256 0.0f
 #endif
 #ifndef PF_IGEMM_GROUP_M
 #define PF_IGEMM_GROUP_M 8
@@ -117,15 +120,17 @@ __device__ __forceinline__ void tile_of(int bid, int mt, int nt, int& tile_m, in
 }
 
 template <typename T, int BM, int BN, int WM, int WN, bool RELU_IN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p) {
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const pf_conv_params p) {
   constexpr int VEC = Elem<T>::VEC;
   constexpr int BK = 8 * VEC;  // elements per 128-byte chunk row
+  constexpr int NW = WM * WN;  // waves: 4 (two or more blocks per CU) or 8 (the 256x256 tile, one block per CU)
+  constexpr int RP = 8 * NW;   // tile rows moved per loader pass (one 1-KiB LDS-DMA piece = 8 rows per wave)
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int FM = WTM / 16, FN = WTN / 16;
-  constexpr int A_ITERS = (BM + 31) / 32, B_ITERS = (BN + 31) / 32;
-  constexpr int A_BYTES = BM * 128, B_BYTES = ((BN + 31) / 32) * 32 * 128, STAGE = A_BYTES + B_BYTES;
-  static_assert(WM * WN == 4, "4 waves");
-  static_assert(WTM % 16 == 0 && WTN % 16 == 0 && BM % 32 == 0, "fragment multiple");
+  constexpr int A_ITERS = (BM + RP - 1) / RP, B_ITERS = (BN + RP - 1) / RP;
+  constexpr int A_BYTES = BM * 128, B_BYTES = B_ITERS * RP * 128, STAGE = A_BYTES + B_BYTES;
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  static_assert(WTM % 16 == 0 && WTN % 16 == 0 && BM % RP == 0, "fragment multiple");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
   unsigned a_mask[A_ITERS];
 #pragma unroll
   for (int i = 0; i < A_ITERS; ++i) {
-    const int m = m0 + r0 + 32 * i;
+    const int m = m0 + r0 + RP * i;
     a_mask[i] = 0u;
     a_ptr[i] = zero;
     if (m < M) {
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
   const char* b_ptr[B_ITERS];
 #pragma unroll
   for (int i = 0; i < B_ITERS; ++i) {
-    const int row = n0 + r0 + 32 * i;
+    const int row = n0 + r0 + RP * i;
     b_ptr[i] = (row < p.w_rows) ? reinterpret_cast<const char*>(wg + (long)row * p.Kpad + j * VEC) : nullptr;
   }
   const int cin_v = p.Cin / VEC;
@@ -211,12 +216,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
     if (fast) {
 #pragma unroll
       for (int i = 0; i < A_ITERS; ++i) {
-        glds16(a_cur[i], As + i * (32 * 128));
+        glds16(a_cur[i], As + i * (RP * 128));
         a_cur[i] += a_inc[i];
       }
 #pragma unroll
       for (int i = 0; i < B_ITERS; ++i) {
-        glds16(b_cur[i], Bs + i * (32 * 128));
+        glds16(b_cur[i], Bs + i * (RP * 128));
         b_cur[i] += b_inc[i];
       }
       return;
@@ -226,12 +231,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
     for (int i = 0; i < A_ITERS; ++i) {
       const bool ok = (a_mask[i] >> tap) & 1u;
       const char* src = ok ? a_ptr[i] + koff : zero;
-      glds16(src, As + i * (32 * 128));
+      glds16(src, As + i * (RP * 128));
     }
 #pragma unroll
     for (int i = 0; i < B_ITERS; ++i) {
       const char* src = b_ptr[i] ? b_ptr[i] + (long)kc * (BK * (long)sizeof(T)) : zero;
-      glds16(src, Bs + i * (32 * 128));
+      glds16(src, Bs + i * (RP * 128));
     }
     // advance this thread's K position by one chunk (8 vectors)
     if (p.korder) {
@@ -257,13 +262,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
   const int fr = lane & 15, fg = lane >> 4;
   // per-channel epilogue constants are fetched NOW: their global-load latency (1-2 us, once per block, a tenth of
   // a K=1024 GEMM block's life) hides behind the K loop instead of sitting between the last MFMA and the stores
+  constexpr bool kPreload = FN <= 4;    // (wide tiles: 2 x FN float4 registers do not fit next to 128 accumulator registers)
   float4 bias_r[FN], scale_r[FN];
 #pragma unroll
   for (int fn = 0; fn < FN; ++fn) {
     const int n = n0 + wn * WTN + fn * 16 + fg * 4;
     bias_r[fn] = make_float4(0.f, 0.f, 0.f, 0.f);
     scale_r[fn] = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (p.shuffle <= 1 && n < p.Cout) {
+    if (kPreload && p.shuffle <= 1 && n < p.Cout) {
       if (p.bias) bias_r[fn] = *reinterpret_cast<const float4*>(p.bias + n);
       if (p.scale) scale_r[fn] = *reinterpret_cast<const float4*>(p.scale + n);
     }
@@ -312,6 +318,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pf_conv_params p)
   }
 
   // ---- epilogue: bias -> act -> scale -> residual(s) -> store 4 consecutive channels ----
+  if constexpr (!kPreload) {
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) {
+      const int n = n0 + wn * WTN + fn * 16 + fg * 4;
+      if (p.shuffle <= 1 && n < p.Cout) {
+        if (p.bias) bias_r[fn] = *reinterpret_cast<const float4*>(p.bias + n);
+        if (p.scale) scale_r[fn] = *reinterpret_cast<const float4*>(p.scale + n);
+      }
+    }
+  }
   const int s = p.shuffle > 1 ? p.shuffle : 1;
   const int cout_t = p.Cout / (s * s);
 #pragma unroll
@@ -1280,13 +1296,14 @@ thread_local char g_err[256] = {0};
 
 template <typename T, int BM, int BN, int WM, int WN, bool RELU_IN>
 int launch_cfg2(const pf_conv_params& p, hipStream_t st) {
-  constexpr int smem = 2 * (BM + ((BN + 31) / 32) * 32) * 128;
+  constexpr int RP = 8 * WM * WN;
+  constexpr int smem = 2 * (BM + ((BN + RP - 1) / RP) * RP) * 128;
   static std::atomic<unsigned long long> attr_done{0};
   auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, RELU_IN>;
   ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
   const long M = (long)p.B * p.OH * p.OW;
   const long mt = (M + BM - 1) / BM, nt = (p.Cout + BN - 1) / BN;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(mt * nt)), dim3(256), smem, st, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(mt * nt)), dim3(64 * WM * WN), smem, st, p);
   return launch_status();
 }
 
@@ -1337,7 +1354,7 @@ int dispatch(const pf_conv_params& p, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
     // persistent GEMM (see gemm_persist_kernel; validated by tests/test_persistent_gemm_gpu.py).
     // PF_GEMM_PERSIST (read per call): 0 = off, 1 = every eligible layer with the shape picked by the makespan model below,
-    // or force "BMxBN" by its code 128128 / 12896 / 12864 / 144128 / 14464.
+    // or force "BMxBN" by its code 128128 / 12896 / 12864 / 144128 / 14464 / 256128.
     const char* pe = getenv("PF_GEMM_PERSIST");
     // default: on for the wide linears (Cout >= 2048: ViT qkv / fc1, +2 ... +16 % measured, profiles/r2_sweep_bf16*.log);
     // the narrow ones (proj, fc2: 520 tiles on 512 resident blocks) measured +-2 % and keep the one-tile kernel
@@ -1350,20 +1367,18 @@ int dispatch(const pf_conv_params& p, hipStream_t st) {
       // eff: relative matrix-pipe efficiency of a tile shape once resident (the 128-row tiles are bound by the texture-address
       // path: 32 KB of LDS-DMA per 512 MFMA cycles; a 256x256 tile moves half the bytes per MFMA) -- calibrated on the ViT-L linears
       struct Cand { int code, bm, bn, occ; float eff; };
-      const Cand cand[7] = {{128128, 128, 128, PersistCfg<128, 128, 2, 2>::occ, 1.f}, {12896, 128, 96, PersistCfg<128, 96, 2, 2>::occ, 1.f},
+      const Cand cand[6] = {{128128, 128, 128, PersistCfg<128, 128, 2, 2>::occ, 1.f}, {12896, 128, 96, PersistCfg<128, 96, 2, 2>::occ, 1.f},
                             {12864, 128, 64, PersistCfg<128, 64, 2, 2>::occ, 1.f}, {144128, 144, 128, PersistCfg<144, 128, 3, 2>::occ, 1.f},
                             {14464, 144, 64, PersistCfg<144, 64, 3, 2>::occ, 1.f},
-                            {256128, 256, 128, PersistCfg<256, 128, 4, 2>::occ, PF_PERSIST_EFF_256128},
-                            {256256, 256, 256, PersistCfg<256, 256, 4, 2>::occ, PF_PERSIST_EFF_256256}};
+                            {256128, 256, 128, PersistCfg<256, 128, 4, 2>::occ, PF_PERSIST_EFF_256128}};
       int code = persist;
       bool known = false;
-      for (int i = 0; i < 7; ++i) known = known || cand[i].code == code;
+      for (int i = 0; i < 6; ++i) known = known || cand[i].code == code;
       if (!known) {
         double best = 1e300;
-        for (int i = 0; i < 7; ++i) {
+        for (int i = 0; i < 6; ++i) {
           const long tiles = ((M + cand[i].bm - 1) / cand[i].bm) * ((p.Cout + cand[i].bn - 1) / cand[i].bn);
           const long rounds = (tiles + 256L * cand[i].occ - 1) / (256L * cand[i].occ);
-          if (cand[i].eff <= 0.f) continue;
           const double cost = (double)rounds * cand[i].occ * cand[i].bm * cand[i].bn / cand[i].eff;
           if (cost < best) { best = cost; code = cand[i].code; }
         }
@@ -1376,7 +1391,6 @@ int dispatch(const pf_conv_params& p, hipStream_t st) {
       PF_PERSIST_CASE(144128, 144, 128, 3, 2)
       PF_PERSIST_CASE(14464, 144, 64, 3, 2)
       PF_PERSIST_CASE(256128, 256, 128, 4, 2)
-      PF_PERSIST_CASE(256256, 256, 256, 4, 2)
 #undef PF_PERSIST_CASE
     }
   }
@@ -1387,8 +1401,9 @@ int dispatch(const pf_conv_params& p, hipStream_t st) {
 // cost ~ makespan of `blocks` tiles on 256 CUs with `occ` co-resident blocks each (blocks / slots full rounds + a tail
 // round), times the per-round cost bm*bn*occ, over a small per-shape efficiency factor.
 struct TileCfg { int bm, bn, occ; float eff; int id; };
-static const TileCfg kCfgs[7] = {{256, 128, 1, 1.0f, 0}, {128, 128, 2, 1.0f, 1}, {128, 96, 2, 0.97f, 2},
-                                 {128, 64, 3, 0.96f, 3}, {256, 32, 2, 0.75f, 4}, {256, 16, 2, 0.5f, 5}, {64, 64, 4, 0.92f, 6}};
+static const TileCfg kCfgs[8] = {{256, 128, 1, 1.0f, 0}, {128, 128, 2, 1.0f, 1}, {128, 96, 2, 0.97f, 2},
+                                 {128, 64, 3, 0.96f, 3}, {256, 32, 2, 0.75f, 4}, {256, 16, 2, 0.5f, 5}, {64, 64, 4, 0.92f, 6},
+                                 {256, 256, 1, PF_F32_EFF_256, 7}};   // id 7: f32 only, eight waves (half the LDS-DMA pieces per MFMA)
 
 template <typename T>
 static double cfg_cost(const TileCfg& c, long M, int cout) {
@@ -1400,10 +1415,11 @@ template <typename T>
 static int best_cfg(const pf_conv_params& p, long M, int cout, double* cost_out) {
   int best = -1;
   double best_cost = 1e300;
-  for (int i = 0; i < 7; ++i) {
+  for (int i = 0; i < 8; ++i) {
     const TileCfg& c = kCfgs[i];
     if (c.id == 0 && (sizeof(T) != 2 || g_force_small == 1 || cout < 96)) continue;   // big kernel: bf16 only
     if (c.id == 6 && sizeof(T) != 4) continue;                                        // 64x64: f32 granularity tile
+    if (c.id == 7 && (sizeof(T) != 4 || c.eff <= 0.f || cout % 256 || p.shuffle > 1)) continue;   // 256x256: f32, exact channel multiples
     const double cost = cfg_cost<T>(c, M, cout);
     if (cost < best_cost) { best_cost = cost; best = c.id; }
   }
@@ -1420,6 +1436,7 @@ int launch_generic(const pf_conv_params& p, hipStream_t st, int cfg) {
     case 3: return launch_cfg<T, 128, 64, 2, 2>(p, st);
     case 4: return launch_cfg<T, 256, 32, 4, 1>(p, st);
     case 6: if constexpr (sizeof(T) == 4) return launch_cfg<T, 64, 64, 2, 2>(p, st);
+    case 7: if constexpr (sizeof(T) == 4) return launch_cfg<T, 256, 256, 4, 2>(p, st);
     default: return launch_cfg<T, 256, 16, 4, 1>(p, st);
   }
 }
@@ -1437,13 +1454,15 @@ int dispatch_generic(const pf_conv_params& p, hipStream_t st, bool allow_split) 
   const int no_split = e2 ? atoi(e2) : 0;
   double cost_single;
   int best = best_cfg<T>(p, M, p.Cout, &cost_single);
-  if (force_cfg >= 0 && !(force_cfg == 0 && sizeof(T) != 2) && !(force_cfg == 6 && sizeof(T) != 4)) return launch_generic<T>(p, st, force_cfg);
+  if (force_cfg >= 0 && !(force_cfg == 0 && sizeof(T) != 2) && !(force_cfg >= 6 && sizeof(T) != 4)) return launch_generic<T>(p, st, force_cfg);
   if constexpr (sizeof(T) == 4) {
     if (allow_split && !no_split && p.shuffle <= 1 && p.Cout > 128) {
       int split_at = 0, split_cfg = -1;
       double split_cost = cost_single * 0.985;        // a second launch must buy at least 1.5 %
-      for (int i = 1; i <= 3; ++i) {                  // body tiles 128x128 / 128x96 / 128x64
+      for (int i = 1; i <= 7; ++i) {                  // body tiles 128x128 / 128x96 / 128x64 / 256x256
+        if (i > 3 && i < 7) continue;
         const TileCfg& c = kCfgs[i];
+        if (i == 7 && c.eff <= 0.f) continue;
         const int body = (p.Cout / c.bn) * c.bn, rem = p.Cout - body;
         if (body == 0 || rem == 0) continue;
         double rem_cost;

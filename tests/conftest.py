@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# The reference side of the GPU tests (oracle / plain-PyTorch ops) runs torch's MIOpen convolutions; on a fresh box MIOpen's
+# exhaustive per-shape solver search costs minutes.  Immediate-mode heuristics are enough for a checker (the product path does
+# not use MIOpen at all).
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

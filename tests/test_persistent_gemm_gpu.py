@@ -2,10 +2,10 @@
 default for the wide 1x1 / linear layers (Cout >= 2048: ViT qkv, fc1).
 
 PF_GEMM_PERSIST (read per call: 0 = off, 1 = every eligible layer with the shape chosen by the makespan model, or a forced
-shape code 128128 / 12896 / 12864 / 144128 / 14464 / 256128 / 256256 = BMxBN) routes every bf16 1x1 / linear layer with Cin % 64 == 0,
+shape code 128128 / 12896 / 12864 / 144128 / 14464 / 256128 = BMxBN) routes every bf16 1x1 / linear layer with Cin % 64 == 0,
 Cin >= 128, Cout >= 64 and >= 1024 rows to it.  Every shape mode x every case below passed on hardware in round 2
 (gpurun_out/r2_experimental.log: 48 passed; r2c9_persist_tests.log: 24 passed incl. the 256-row shapes); the default run
-keeps the model-chosen shape and the 256x128 eight-wave shape (PF_TEST_ALL_PERSIST_SHAPES=1 runs all eight modes).
+keeps the model-chosen shape and the 256x128 eight-wave shape (PF_TEST_ALL_PERSIST_SHAPES=1 runs all seven modes).
 """
 import os
 
@@ -13,7 +13,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-ALL_MODES = ["1", "128128", "12896", "12864", "144128", "14464", "256128", "256256"]
+ALL_MODES = ["1", "128128", "12896", "12864", "144128", "14464", "256128"]
 MODES = ALL_MODES if os.environ.get("PF_TEST_ALL_PERSIST_SHAPES") == "1" else ["1", "256128"]
 
 

@@ -24,7 +24,7 @@ for name, (B, H, W), cin, cout, k in SHAPES:
     fl = 2.0 * B * H * W * cin * k * k * cout
     ref = None
     for pipe in ("0",):
-        for cfg in ("", "1", "2", "3", "6"):
+        for cfg in ("", "1", "3", "6", "7"):
             os.environ["PF_F32_WS"] = pipe
             if cfg:
                 os.environ["PF_IGEMM_CFG"] = cfg

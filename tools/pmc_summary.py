@@ -1,8 +1,10 @@
 """Summarise rocprofv3 --pmc passes of ONE kernel (the dominant launch of `bench.py --roofline-only`) into a JSON for profiles/.
 
 usage: python tools/pmc_summary.py <dtype> <kernel-substring> <out.json> <pass_dir> [<pass_dir> ...]
-Every pass dir holds *_counter_collection.csv of one `rocprofv3 --pmc ... --kernel-trace --output-format csv` run.
-Counters are averaged over the dispatches of the matching kernel with the LARGEST grid (the roofline launch).
+Every pass dir holds *_counter_collection.csv of one `rocprofv3 --pmc ... --kernel-trace --output-format csv` run of
+`bench.py --roofline-only`, which calls pf_conv CALLS = 6 times (1 warm-up + 5 timed).  One pf_conv call may be several
+dispatches (the f32 channel split: body + remainder), so every counter is SUMMED over all matching dispatches of a pass and
+divided by CALLS -> per pf_conv launch, the same unit as roofline.achieved.
 Units (MI355X_MICROARCH.md): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves;
 SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs;
 FETCH_SIZE (KB) reports 1/2 of a wide coalesced read stream on gfx950 -> doubled; WRITE_SIZE (KB) as is.
@@ -25,23 +27,34 @@ def main():
     for d in sys.argv[4:]:
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             with open(f) as fh:
-                rows += [r for r in csv.DictReader(fh) if sub in r["Kernel_Name"]]
+                for r in csv.DictReader(fh):
+                    if sub in r["Kernel_Name"]:
+                        r["__pass"] = d
+                        rows.append(r)
     if not rows:
         print("no rows for", sub)
         return
-    grid = max(int(r["Grid_Size"]) for r in rows)
-    name = ""
+    CALLS = 6
+    name = sorted({r["Kernel_Name"] for r in rows}, key=len)[0]
+    seen = defaultdict(set)
+    tot = defaultdict(float)
+    dur_by_pass = defaultdict(float)
     for r in rows:
-        if int(r["Grid_Size"]) != grid:
-            continue
-        name = r["Kernel_Name"]
-        vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
-        durs.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
-    per = {k: sum(v) / len(v) for k, v in vals.items()}
-    ms = sum(durs) / len(durs)
+        key = (r["__pass"], r["Dispatch_Id"])
+        tot[r["Counter_Name"]] += float(r["Counter_Value"])
+        if key not in seen["d"]:
+            seen["d"].add(key)
+            dur_by_pass[r["__pass"]] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+    # a counter lives in exactly one pass -> its sum over that pass / CALLS
+    per = {k: v / CALLS for k, v in tot.items()}
+    ms = sum(dur_by_pass.values()) / len(dur_by_pass) / CALLS
+    durs = list(seen["d"])
+    grid = sorted({int(r["Grid_Size"]) for r in rows})
     der = {"ms_per_launch_profiled": ms}
     if "GRBM_GUI_ACTIVE" in per:
-        cyc = per["GRBM_GUI_ACTIVE"] / 8.0
+        # GRBM_GUI_ACTIVE may be collected in several passes: use the mean per pass
+        n_grbm = sum(1 for d in dur_by_pass if any(r["__pass"] == d and r["Counter_Name"] == "GRBM_GUI_ACTIVE" for r in rows))
+        cyc = per["GRBM_GUI_ACTIVE"] / max(n_grbm, 1) / 8.0
         der["kernel_cycles_per_xcd"] = cyc
         der["effective_clock_GHz"] = cyc / (ms * 1e-3) / 1e9
         if "SQ_VALU_MFMA_BUSY_CYCLES" in per:
@@ -60,7 +73,7 @@ def main():
     h = hashlib.sha256()
     for f in ("igemm.hip", "pf_common.h"):
         h.update(open(os.path.join(ROOT, "patchfusion_amd", "csrc", f), "rb").read())
-    j = {"kernel": name, "grid": grid, "dtype": dtype, "kernel_source_sha": h.hexdigest()[:12], "dispatches_averaged": len(durs),
+    j = {"kernel": name, "grid": grid, "dtype": dtype, "kernel_source_sha": h.hexdigest()[:12], "dispatches_total_all_passes": len(durs), "pf_conv_calls_per_pass": 6,
          "command": "rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python bench.py --roofline-only --dtype " + dtype,
          "per_launch": per, "derived": der}
     json.dump(j, open(out, "w"), indent=1)

@@ -98,8 +98,9 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 #ifndef PF_PERSIST_EFF_256128
 #define PF_PERSIST_EFF_256128 1.25f
 #endif
-#ifndef PF_F32_EFF_256      // relative efficiency of the eight-wave 256x256 f32 tile in the cost model; 0 = forced (PF_IGEMM_CFG=7) only
-#define PF_F32_EFF_256 0.0f
+#ifndef PF_F32_EFF_256      // relative efficiency of the eight-wave 256x256 f32 tile in the cost model (measured +2.2 % on 3x3 768->768 @ 8x224x296,
+                            // profiles/r2_f32_tune_256.log; loses on small M, which the tail term of the model covers); 0 = forced only
+#define PF_F32_EFF_256 1.03f
 #endif
 #ifndef PF_IGEMM_GROUP_M
 #define PF_IGEMM_GROUP_M 8

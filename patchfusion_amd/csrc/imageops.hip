@@ -40,27 +40,31 @@ __device__ __forceinline__ void st8x(void* p, long off, int f32, const float (&v
   else store8(reinterpret_cast<T*>(p) + off, v);
 }
 
+// One (batch, output row) per blockIdx.y: the vertical taps are block-uniform (scalar), the loop index decomposes into
+// (column, channel vector) with one 32-bit division by the channel-vector count -- the old flat grid-stride loop spent its
+// time in three 64-bit divisions per 16-byte store (27-37 % of the HBM roofline, profiles/r2a_op_roofline_*.md).
 template <typename T>
 __global__ void resize_bilinear_kernel(const void* __restrict__ x, int x_ld, int B, int H, int W, int C, void* __restrict__ y,
                                        int y_ld, int OH, int OW, const void* __restrict__ add, int add_ld, int in_f32,
                                        int out_f32, float sh, float sw) {
   const int cv = C >> 3;
-  const long total = (long)B * OH * OW * cv;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int v = (int)(i % cv);
-    long pix = i / cv;
-    const int ox = (int)(pix % OW);
-    const int oy = (int)((pix / OW) % OH);
-    const int b = (int)(pix / ((long)OW * OH));
-    const Lerp ly = ac_coord(oy, sh, H), lx = ac_coord(ox, sw, W);
-    const long base = (long)b * H * W;
+  const int n = OW * cv;
+  for (int row = blockIdx.y; row < B * OH; row += gridDim.y) {      // row = b * OH + oy
+  const int b = row / OH, oy = row - b * OH;
+  const Lerp ly = ac_coord(oy, sh, H);
+  const long r0 = ((long)b * H + ly.i0) * W, r1 = ((long)b * H + ly.i1) * W;
+  const long orow = (long)row * OW;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int ox = i / cv, v = i - ox * cv;
+    const Lerp lx = ac_coord(ox, sw, W);
     float v00[8], v01[8], v10[8], v11[8], o[8];
-    ld8x<T>(x, (base + (long)ly.i0 * W + lx.i0) * x_ld + v * 8, in_f32, v00);
-    ld8x<T>(x, (base + (long)ly.i0 * W + lx.i1) * x_ld + v * 8, in_f32, v01);
-    ld8x<T>(x, (base + (long)ly.i1 * W + lx.i0) * x_ld + v * 8, in_f32, v10);
-    ld8x<T>(x, (base + (long)ly.i1 * W + lx.i1) * x_ld + v * 8, in_f32, v11);
+    ld8x<T>(x, (r0 + lx.i0) * x_ld + v * 8, in_f32, v00);
+    ld8x<T>(x, (r0 + lx.i1) * x_ld + v * 8, in_f32, v01);
+    ld8x<T>(x, (r1 + lx.i0) * x_ld + v * 8, in_f32, v10);
+    ld8x<T>(x, (r1 + lx.i1) * x_ld + v * 8, in_f32, v11);
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = ly.l0 * (lx.l0 * v00[e] + lx.l1 * v01[e]) + ly.l1 * (lx.l0 * v10[e] + lx.l1 * v11[e]);
+    const long pix = orow + ox;
     if (add) {
       float a[8];
       ld8x<T>(add, pix * add_ld + v * 8, out_f32, a);
@@ -68,6 +72,7 @@ __global__ void resize_bilinear_kernel(const void* __restrict__ x, int x_ld, int
       for (int e = 0; e < 8; ++e) o[e] = a[e] + o[e];
     }
     st8x<T>(y, pix * y_ld + v * 8, out_f32, o);
+  }
   }
 }
 
@@ -84,26 +89,25 @@ __global__ void resize_concat_kernel(ResizeSrc s0, ResizeSrc s1, ResizeSrc s2, i
                                      int OH, int OW) {
   const int cv0 = s0.C >> 3, cv1 = s1.C >> 3, cv2 = nsrc > 2 ? (s2.C >> 3) : 0;
   const int cv = cv0 + cv1 + cv2;
-  const long total = (long)B * OH * OW * cv;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int v = (int)(i % cv);
-    const long pix = i / cv;
-    const int ox = (int)(pix % OW);
-    const int oy = (int)((pix / OW) % OH);
-    const int b = (int)(pix / ((long)OW * OH));
-    const int vout = v;
-    const ResizeSrc& s = v < cv0 ? s0 : (v < cv0 + cv1 ? s1 : s2);
-    v -= v < cv0 ? 0 : (v < cv0 + cv1 ? cv0 : cv0 + cv1);
+  const int n = OW * cv;
+  for (int row = blockIdx.y; row < B * OH; row += gridDim.y) {      // row = b * OH + oy
+  const int b = row / OH, oy = row - b * OH;
+  const long orow = (long)row * OW;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int ox = i / cv, vout = i - ox * cv;
+    const ResizeSrc& s = vout < cv0 ? s0 : (vout < cv0 + cv1 ? s1 : s2);
+    const int v = vout - (vout < cv0 ? 0 : (vout < cv0 + cv1 ? cv0 : cv0 + cv1));
     const Lerp ly = ac_coord(oy, s.sh, s.H), lx = ac_coord(ox, s.sw, s.W);
-    const long base = (long)b * s.H * s.W;
+    const long r0 = ((long)b * s.H + ly.i0) * s.W, r1 = ((long)b * s.H + ly.i1) * s.W;
     float v00[8], v01[8], v10[8], v11[8], o[8];
-    ld8x<T>(s.x, (base + (long)ly.i0 * s.W + lx.i0) * s.ld + v * 8, 0, v00);
-    ld8x<T>(s.x, (base + (long)ly.i0 * s.W + lx.i1) * s.ld + v * 8, 0, v01);
-    ld8x<T>(s.x, (base + (long)ly.i1 * s.W + lx.i0) * s.ld + v * 8, 0, v10);
-    ld8x<T>(s.x, (base + (long)ly.i1 * s.W + lx.i1) * s.ld + v * 8, 0, v11);
+    ld8x<T>(s.x, (r0 + lx.i0) * s.ld + v * 8, 0, v00);
+    ld8x<T>(s.x, (r0 + lx.i1) * s.ld + v * 8, 0, v01);
+    ld8x<T>(s.x, (r1 + lx.i0) * s.ld + v * 8, 0, v10);
+    ld8x<T>(s.x, (r1 + lx.i1) * s.ld + v * 8, 0, v11);
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = ly.l0 * (lx.l0 * v00[e] + lx.l1 * v01[e]) + ly.l1 * (lx.l0 * v10[e] + lx.l1 * v11[e]);
-    st8x<T>(y, pix * y_ld + vout * 8, 0, o);
+    st8x<T>(y, (orow + ox) * y_ld + vout * 8, 0, o);
+  }
   }
 }
 
@@ -439,11 +443,19 @@ __global__ void resize_bilinear_f32_kernel(const float* __restrict__ x, int H, i
     else hipLaunchKernelGGL(kern<float>, dim3(grid_for(total, 256)), dim3(256), 0, ST(stream), __VA_ARGS__);            \
   } while (0)
 
+// one block row per (batch, output row); x covers the row's (column, channel-vector) items
+#define LAUNCH_ROWS(kern, rows, items, ...)                                                                             \
+  do {                                                                                                                  \
+    const dim3 g((unsigned)(((items) + 255) / 256 > 64 ? 64 : ((items) + 255) / 256), (unsigned)((rows) > 65535 ? 65535 : (rows))); \
+    if (dtype == PF_DTYPE_BF16) hipLaunchKernelGGL(kern<bf16_t>, g, dim3(256), 0, ST(stream), __VA_ARGS__);             \
+    else hipLaunchKernelGGL(kern<float>, g, dim3(256), 0, ST(stream), __VA_ARGS__);                                     \
+  } while (0)
+
 extern "C" int pf_resize_bilinear(const void* x, int x_ld, int B, int H, int W, int C, void* y, int y_ld, int OH, int OW,
                                   const void* add, int add_ld, int in_f32, int out_f32, int dtype, void* stream) {
   if (!x || !y || C % 8 || x_ld % 8 || y_ld % 8 || (add && add_ld % 8)) return PF_ERR_ARG;
-  const long total = (long)B * OH * OW * (C / 8);
-  LAUNCH_T(resize_bilinear_kernel, total, x, x_ld, B, H, W, C, y, y_ld, OH, OW, add, add_ld, in_f32, out_f32, ac_scale(H, OH), ac_scale(W, OW));
+  LAUNCH_ROWS(resize_bilinear_kernel, B * OH, OW * (C / 8), x, x_ld, B, H, W, C, y, y_ld, OH, OW, add, add_ld, in_f32, out_f32,
+              ac_scale(H, OH), ac_scale(W, OW));
   return ok();
 }
 
@@ -457,8 +469,7 @@ extern "C" int pf_resize_concat(const void* const* xs, const int* lds, const int
     s[i] = ResizeSrc{xs[i], lds[i], Hs[i], Ws[i], Cs[i], ac_scale(Hs[i], OH), ac_scale(Ws[i], OW)};
     cv += Cs[i] / 8;
   }
-  const long total = (long)B * OH * OW * cv;
-  LAUNCH_T(resize_concat_kernel, total, s[0], s[1], s[2], nsrc, B, y, y_ld, OH, OW);
+  LAUNCH_ROWS(resize_concat_kernel, B * OH, OW * (int)cv, s[0], s[1], s[2], nsrc, B, y, y_ld, OH, OW);
   return ok();
 }
 

@@ -156,7 +156,7 @@ template <typename T> __device__ __forceinline__ int attn_swz(int row, int slot)
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void vit_attention_kernel(const T* __restrict__ q, const T* __restrict__ k,
+__global__ __launch_bounds__(256, 2) void vit_attention_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                             const T* __restrict__ vt, T* __restrict__ out, int B, int S,
                                                             int Sp, int Hh) {
   constexpr int ROWB = AttnCfg<T>::ROWB, SPR = AttnCfg<T>::SPR;
@@ -190,46 +190,62 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const T* __restrict_
   float m_run = -INFINITY, l_run = 0.f;
 
   const int ntiles = (S + 63) / 64;
+  // K tile [64 keys][64 d] and V^T tile [64 d][64 keys] go global -> registers -> LDS; the global loads of tile kt+1 are issued
+  // BEFORE tile kt is multiplied, so their latency overlaps the 128 MFMAs of the tile instead of sitting between two barriers
+  constexpr int RPP = 256 / SPR, NPASS = 64 / RPP;        // rows per pass, passes
+  const int sj = tid % SPR, srr0 = tid / SPR;
+  typedef unsigned __attribute__((ext_vector_type(4))) u32x4v;   // (native vector: HIP's uint4 struct arrays ended up in scratch here)
+  u32x4v kreg[NPASS], vreg[NPASS];
+#define PF_ATTN_GLOAD(KT)                                                                                   \
+  _Pragma("unroll") for (int i = 0; i < NPASS; ++i) {                                                       \
+    const int row = srr0 + RPP * i;                                                                         \
+    const int key = (KT) * 64 + row;                                                                        \
+    const u32x4v kv = *reinterpret_cast<const u32x4v*>(kb + (long)min(key, S - 1) * 64 + sj * VEC);        \
+    kreg[i] = key < S ? kv : u32x4v{0u, 0u, 0u, 0u};                                                        \
+    vreg[i] = *reinterpret_cast<const u32x4v*>(vb + (long)row * Sp + (KT) * 64 + sj * VEC);                 \
+  }
+  PF_ATTN_GLOAD(0)
   for (int kt = 0; kt < ntiles; ++kt) {
-    __syncthreads();
-    // ---- stage K tile [64 keys][64 d] and V^T tile [64 d][64 keys] ----
-    {
-      constexpr int RPP = 256 / SPR;  // rows per pass
-      const int j = tid % SPR, rr0 = tid / SPR;
+    __syncthreads();                                      // every wave has finished reading tile kt-1
 #pragma unroll
-      for (int i = 0; i < 64 / RPP; ++i) {
-        const int row = rr0 + RPP * i;
-        const int key = kt * 64 + row;
-        uint4 kv = make_uint4(0, 0, 0, 0);
-        if (key < S) kv = *reinterpret_cast<const uint4*>(kb + (long)key * 64 + j * VEC);
-        *reinterpret_cast<uint4*>(Ks + row * ROWB + (attn_swz<T>(row, j) << 4)) = kv;
-        const uint4 vv = *reinterpret_cast<const uint4*>(vb + (long)row * Sp + kt * 64 + j * VEC);
-        *reinterpret_cast<uint4*>(Vs + row * ROWB + (attn_swz<T>(row, j) << 4)) = vv;
-      }
+    for (int i = 0; i < NPASS; ++i) {
+      const int row = srr0 + RPP * i;
+      *reinterpret_cast<u32x4v*>(Ks + row * ROWB + (attn_swz<T>(row, sj) << 4)) = kreg[i];
+      *reinterpret_cast<u32x4v*>(Vs + row * ROWB + (attn_swz<T>(row, sj) << 4)) = vreg[i];
     }
     __syncthreads();
+    if (kt + 1 < ntiles) { PF_ATTN_GLOAD(kt + 1) }
     // ---- S^T = K Q^T ----
     f32x4 sc[4];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      sc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int row = f * 16 + r;
-      if constexpr (sizeof(T) == 2) {
+    for (int f = 0; f < 4; ++f) sc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const int row = f * 16 + r;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           const uint4 a = *reinterpret_cast<const uint4*>(Ks + row * ROWB + (attn_swz<T>(row, ks * 4 + g) << 4));
           sc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, qf[ks]),
                                                          sc[f], 0, 0, 0);
         }
-      } else {
+      }
+    } else {
+      // the four key fragments are four INDEPENDENT accumulator chains: walk them round-robin (f innermost) so that no
+      // v_mfma_f32_16x16x4_f32 waits for its predecessor (40-cycle dependent latency against a 32-cycle issue interval)
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-          const uint4 a = *reinterpret_cast<const uint4*>(Ks + row * ROWB + (attn_swz<T>(row, s4 * 4 + g) << 4));
-          sc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(qf[s4].x), sc[f], 0, 0, 0);
-          sc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(qf[s4].y), sc[f], 0, 0, 0);
-          sc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(qf[s4].z), sc[f], 0, 0, 0);
-          sc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(qf[s4].w), sc[f], 0, 0, 0);
-        }
+      for (int s4 = 0; s4 < 4; ++s4) {
+        uint4 a[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) a[f] = *reinterpret_cast<const uint4*>(Ks + (f * 16 + r) * ROWB + (attn_swz<T>(f * 16 + r, s4 * 4 + g) << 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int f = 0; f < 4; ++f) {
+            const uint32_t av = e == 0 ? a[f].x : e == 1 ? a[f].y : e == 2 ? a[f].z : a[f].w;
+            const uint32_t qv = e == 0 ? qf[s4].x : e == 1 ? qf[s4].y : e == 2 ? qf[s4].z : qf[s4].w;
+            sc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av), __uint_as_float(qv), sc[f], 0, 0, 0);
+          }
       }
     }
     // ---- online softmax for query (lane & 15); this lane holds keys kt*64 + f*16 + g*4 + e ----
@@ -285,18 +301,20 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const T* __restrict_
     } else {
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
+        uint4 a[4];
 #pragma unroll
-        for (int fd = 0; fd < 4; ++fd) {
-          const int row = fd * 16 + r;
-          const uint4 a = *reinterpret_cast<const uint4*>(Vs + row * ROWB + (attn_swz<T>(row, f * 4 + g) << 4));
-          o[fd] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), sc[f][0], o[fd], 0, 0, 0);
-          o[fd] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), sc[f][1], o[fd], 0, 0, 0);
-          o[fd] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), sc[f][2], o[fd], 0, 0, 0);
-          o[fd] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), sc[f][3], o[fd], 0, 0, 0);
-        }
+        for (int fd = 0; fd < 4; ++fd) a[fd] = *reinterpret_cast<const uint4*>(Vs + (fd * 16 + r) * ROWB + (attn_swz<T>(fd * 16 + r, f * 4 + g) << 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int fd = 0; fd < 4; ++fd) {      // four independent accumulator chains, round-robin (see the QK loop)
+            const uint32_t av = e == 0 ? a[fd].x : e == 1 ? a[fd].y : e == 2 ? a[fd].z : a[fd].w;
+            o[fd] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av), sc[f][e], o[fd], 0, 0, 0);
+          }
       }
     }
   }
+#undef PF_ATTN_GLOAD
   float l = l_run;
   l += __shfl_xor(l, 16, 64);
   l += __shfl_xor(l, 32, 64);

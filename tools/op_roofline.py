@@ -90,6 +90,12 @@ def work(name, a, k):
         x, y = a[0], a[1]
         add = k.get("add", a[2] if len(a) > 2 else None)
         return "byte", nbytes(x) + nbytes(y) + nbytes(add), f"{tuple(_as4(x).shape)} -> {tuple(_as4(y).shape[1:3])}"
+    if name == "resize_concat":
+        xs, y = a[0], a[1]
+        return "byte", sum(nbytes(x) for x in xs) + nbytes(y, sum(x.shape[-1] for x in xs)), \
+            f"{'+'.join(str(x.shape[-1]) for x in xs)} ch from {tuple(xs[-1].shape[1:3])} -> {tuple(_as4(y).shape[1:3])}"
+    if name == "silog_loss":
+        return "byte", nbytes(a[0]) + nbytes(a[1]), f"{tuple(a[0].shape)}"
     if name == "crop_resize":
         img, boxes, out = a[:3]
         b = boxes.cpu()

@@ -1,10 +1,12 @@
 """pytest -m gpu: the whole PatchFusion hot path on the MI355X HIP engine (through the C ABI) against
  (a) the committed golden fixtures generated from the REFERENCE's own Python (tests/golden/*.npz),
  (b) the oracle restatement (oracle/pf_oracle.py) on the same seeded inputs.
-Stated tolerances on the final metric depth (random-init nets: depth std ~0.01..0.09):
-   fp32 mode: max |d - ref| <= 2e-4 absolute (f32 MFMA = exact fma chain; only summation order differs)
-   bf16 mode: max |d - ref| <= 0.35 * std(ref) and mean |d - ref| <= 0.06 * std(ref)
+Stated tolerances on the final metric depth, in DEPTH UNITS (synthetic-weight nets: depths 0.4..1.0, std 0.011..0.014):
+   fp32 mode: max |d - ref| <= 2e-4 (f32 MFMA = exact fma chain; only summation order differs; measured ~1e-6..1e-5)
+   bf16 mode: max |d - ref| <= 5e-3 and mean |d - ref| <= 6e-4 = 2x the error measured in round 2 (tiny: max 1.7e-3 / mean
+              2.6e-4; ViT-L tiles: max 2.4e-3 / mean 3.1e-4; the configuration the bench times: tests/test_headline_parity_gpu.py)
 """
+BF16_MAX, BF16_MEAN = 5e-3, 6e-4
 import os
 import random
 
@@ -79,7 +81,7 @@ def test_tiny_bf16_within_stated_tolerance(golden_dir):
     ref = g["depth_m1"]
     diff = np.abs(d[0, 0].float().cpu().numpy() - ref)
     print(f"MEASURED tiny bf16 vs reference golden: max {diff.max():.3e} p99 {np.quantile(diff, 0.99):.3e} mean {diff.mean():.3e} std(ref) {ref.std():.3e}")
-    assert diff.max() <= 0.35 * ref.std() and diff.mean() <= 0.06 * ref.std(), (diff.max(), diff.mean(), ref.std())
+    assert diff.max() <= BF16_MAX and diff.mean() <= BF16_MEAN, (diff.max(), diff.mean(), ref.std())
 
 
 def test_full_size_vits_fp32_matches_reference_golden(golden_dir):
@@ -135,7 +137,7 @@ def test_vitl_patch_batch_vs_oracle_on_gpu():
         if dtype == "fp32":
             assert float(diff.max()) <= tol_max and float(diff.mean()) <= tol_mean, (float(diff.max()), float(diff.mean()))
         else:
-            assert float(diff.max()) <= 0.5 * s and float(diff.mean()) <= 0.08 * s, (float(diff.max()), float(diff.mean()), s)
+            assert float(diff.max()) <= BF16_MAX and float(diff.mean()) <= BF16_MEAN, (float(diff.max()), float(diff.mean()), s)
         del m
         torch.cuda.empty_cache()
 
@@ -144,14 +146,15 @@ def test_headline_size_schedule_properties():
     """BASELINE.json configs[2] itself (Depth-Anything ViT-L, 2160x3840, 4x4 tiles, process_num 8, bf16): the oracle
     needs minutes per tile on a CPU, so the full-size pass is checked through size-independent properties
     (tests/schedule_props.py): determinism, stream-schedule invariance (bit-exact), batch-size invariance within the
-    bf16 tolerance of test_vitl_patch_batch_vs_oracle_on_gpu, finite / in-range / reensemble-shaped output."""
+    bf16 budget, finite / in-range / reensemble-shaped output.  (The same configuration is compared with the oracle in
+    tests/test_headline_parity_gpu.py.)"""
     from tests import schedule_props
     cfg, sd, m, img = build("vitl", (392, 518), (2160, 3840), (4, 4), "bf16")
     img = img.cuda()
     lr = m.resizer(img)
-    d = m(mode="infer", image_lr=lr, image_hr=img, cai_mode="m1", process_num=8)[0]
-    s = float(d.float().std())
-    schedule_props.check(m, lr, img, cfg, process_num=8, max_tol=max(0.5 * s, 1e-3), mean_tol=max(0.08 * s, 1e-4))
+    # batch invariance: two bf16 passes whose layers run on different tile shapes (other summation order) may each carry
+    # the bf16 error budget -> allow 1.2x the single-pass budget between them
+    schedule_props.check(m, lr, img, cfg, process_num=8, max_tol=1.2 * BF16_MAX, mean_tol=1.2 * BF16_MEAN)
     del m
     torch.cuda.empty_cache()
 

@@ -1,5 +1,7 @@
-"""Time one conv shape with whatever library PF_LIB_PATH points at (ablation builds of igemm.hip; results are wrong by
-construction, only the time matters).  usage: PF_LIB_PATH=... python tools/abl_run.py <fp32|bf16>"""
+"""Time two conv shapes with whatever library PF_LIB_PATH points at: the compile-time ablation builds of igemm.hip
+(`make -C patchfusion_amd/csrc ablate`, or hipcc -DPF_ABL_NODMA / -DPF_ABL_NOBAR / -DPF_ABL_NOLDS on igemm.hip; their results
+are wrong by construction, only the time matters).  Round-2 numbers: profiles/r2_abl_f32.log.
+usage: PF_LIB_PATH=... [PF_IGEMM_CFG=1] python tools/abl_run.py <fp32|bf16>"""
 import os
 import sys
 

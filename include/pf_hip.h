@@ -39,7 +39,9 @@ int pf_version(void);
  * zoedepth layers localbins_layers.py:87-92,112-116, attractor.py:156-161, dist_layers.py:88-95,
  * estimator/models/patchfusion.py:121-127, blocks/guided_fusion_model.py:41-48,59-66,
  * blocks/swin_layers.py:39-41,125-127.
- * Weights are pre-packed by the host as [w_rows][Kpad] (K order = ky,kx,c; zero padded), in `dtype`.
+ * Weights are pre-packed by the host as [w_rows][Kpad], zero padded, in `dtype`; K order = (ky,kx,c) (`korder` 0) or, for
+ * float32 k x k layers with Cin % 32 == 0, chunk-major (c/32, ky, kx, c%32) (`korder` 1: all taps of one 32-channel chunk
+ * are adjacent, so the re-reads of an input pixel hit L2) -- patchfusion_amd/packing.py.
  */
 typedef struct {
   const void* x; int x_ld; int B, H, W, Cin; /* Cin: valid input channels, multiple of 8 (zero weights on pad) */

@@ -1421,7 +1421,11 @@ static int best_cfg(const pf_conv_params& p, long M, int cout, double* cost_out)
     if (c.id == 0 && (sizeof(T) != 2 || g_force_small == 1 || cout < 96)) continue;   // big kernel: bf16 only
     if (c.id == 6 && sizeof(T) != 4) continue;                                        // 64x64: f32 granularity tile
     if (c.id == 7 && (sizeof(T) != 4 || c.eff <= 0.f || cout % 256 || p.shuffle > 1)) continue;   // 256x256: f32, exact channel multiples
-    const double cost = cfg_cost<T>(c, M, cout);
+    double cost = cfg_cost<T>(c, M, cout);
+    // f32, M below ~300k output pixels (the ViT-L linears at 8296 tokens, the 112x148 / 56x74 pyramid levels): the 64x64
+    // tile measured fastest -- many small blocks beat every "fewer rounds of bigger tiles" candidate, incl. a 144-row
+    // six-wave tile that quantises M = 8296 exactly (profiles/r2_f32_tune_144.log: qkv 109 vs 102 (model's choice) vs 85)
+    if (c.id == 6 && M < 300000) cost *= 0.85;
     if (cost < best_cost) { best_cost = cost; best = c.id; }
   }
   if (cost_out) *cost_out = best_cost;

@@ -15,7 +15,8 @@ from patchfusion_amd.hip_ops import ops  # noqa: E402
 
 dev = torch.device("cuda", 0)
 SHAPES = [("c544_544", (8, 392, 518), 544, 544, 3), ("up4_1", (8, 224, 296), 768, 768, 3), ("c256_L3", (8, 112, 148), 256, 256, 3),
-          ("qkv", (1, 1, 8296), 1024, 3072, 1), ("fc2", (1, 1, 8296), 4096, 1024, 1), ("proj", (1, 1, 8296), 1024, 1024, 1)]
+          ("qkv", (1, 1, 8296), 1024, 3072, 1), ("fc1", (1, 1, 8296), 1024, 4096, 1), ("fc2", (1, 1, 8296), 4096, 1024, 1),
+          ("proj", (1, 1, 8296), 1024, 1024, 1)]
 res = []
 for name, (B, H, W), cin, cout, k in SHAPES:
     g = torch.Generator().manual_seed(5)
@@ -24,7 +25,7 @@ for name, (B, H, W), cin, cout, k in SHAPES:
     pw = pk.pack_conv(w, torch.randn(cout, generator=g), dtype=torch.float32).to(dev)
     fl = 2.0 * B * H * W * cin * k * k * cout
     ref = None
-    for cfg in ("", "1", "2", "3", "6", "7"):
+    for cfg in ("", "1", "3", "6", "7"):
         if cfg:
             os.environ["PF_IGEMM_CFG"] = cfg
         else:

@@ -76,9 +76,9 @@ __global__ void resize_bilinear_kernel(const void* __restrict__ x, int x_ld, int
   }
 }
 
-// Upv1 concat buffer in ONE pass (guided_fusion_model.py:96-99: cat[feat_enc, up(cat[temp, guide])] ): up to three
+// Upv1 concat buffer in ONE launch (guided_fusion_model.py:96-99: cat[feat_enc, up(cat[temp, guide])] ): up to three
 // bilinear (align_corners=True) resizes of different sources / source sizes into consecutive channel ranges of the same
-// NHWC output row, so a wave writes whole contiguous rows instead of three strided channel slices in three launches.
+// NHWC output rows.
 struct ResizeSrc {
   const void* x;
   int ld, H, W, C;
@@ -87,27 +87,33 @@ struct ResizeSrc {
 template <typename T>
 __global__ void resize_concat_kernel(ResizeSrc s0, ResizeSrc s1, ResizeSrc s2, int nsrc, int B, void* __restrict__ y, int y_ld,
                                      int OH, int OW) {
-  const int cv0 = s0.C >> 3, cv1 = s1.C >> 3, cv2 = nsrc > 2 ? (s2.C >> 3) : 0;
-  const int cv = cv0 + cv1 + cv2;
-  const int n = OW * cv;
+  // one (batch, output row) per blockIdx.y; the sources are walked one after the other (block-uniform: the source
+  // descriptor, its vertical taps and its channel offset stay scalar -- a per-thread source select cost more VALU than the
+  // whole-row stores saved, profiles/r2b_op_roofline_fp32.md)
   for (int row = blockIdx.y; row < B * OH; row += gridDim.y) {      // row = b * OH + oy
-  const int b = row / OH, oy = row - b * OH;
-  const long orow = (long)row * OW;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int ox = i / cv, vout = i - ox * cv;
-    const ResizeSrc& s = vout < cv0 ? s0 : (vout < cv0 + cv1 ? s1 : s2);
-    const int v = vout - (vout < cv0 ? 0 : (vout < cv0 + cv1 ? cv0 : cv0 + cv1));
-    const Lerp ly = ac_coord(oy, s.sh, s.H), lx = ac_coord(ox, s.sw, s.W);
-    const long r0 = ((long)b * s.H + ly.i0) * s.W, r1 = ((long)b * s.H + ly.i1) * s.W;
-    float v00[8], v01[8], v10[8], v11[8], o[8];
-    ld8x<T>(s.x, (r0 + lx.i0) * s.ld + v * 8, 0, v00);
-    ld8x<T>(s.x, (r0 + lx.i1) * s.ld + v * 8, 0, v01);
-    ld8x<T>(s.x, (r1 + lx.i0) * s.ld + v * 8, 0, v10);
-    ld8x<T>(s.x, (r1 + lx.i1) * s.ld + v * 8, 0, v11);
+    const int b = row / OH, oy = row - b * OH;
+    const long orow = (long)row * OW;
+    int coff = 0;
+    for (int si = 0; si < nsrc; ++si) {
+      const ResizeSrc& s = si == 0 ? s0 : (si == 1 ? s1 : s2);
+      const int cv = s.C >> 3;
+      const int n = OW * cv;
+      const Lerp ly = ac_coord(oy, s.sh, s.H);
+      const long r0 = ((long)b * s.H + ly.i0) * s.W, r1 = ((long)b * s.H + ly.i1) * s.W;
+      for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int ox = i / cv, v = i - ox * cv;
+        const Lerp lx = ac_coord(ox, s.sw, s.W);
+        float v00[8], v01[8], v10[8], v11[8], o[8];
+        ld8x<T>(s.x, (r0 + lx.i0) * s.ld + v * 8, 0, v00);
+        ld8x<T>(s.x, (r0 + lx.i1) * s.ld + v * 8, 0, v01);
+        ld8x<T>(s.x, (r1 + lx.i0) * s.ld + v * 8, 0, v10);
+        ld8x<T>(s.x, (r1 + lx.i1) * s.ld + v * 8, 0, v11);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = ly.l0 * (lx.l0 * v00[e] + lx.l1 * v01[e]) + ly.l1 * (lx.l0 * v10[e] + lx.l1 * v11[e]);
-    st8x<T>(y, (orow + ox) * y_ld + vout * 8, 0, o);
-  }
+        for (int e = 0; e < 8; ++e) o[e] = ly.l0 * (lx.l0 * v00[e] + lx.l1 * v01[e]) + ly.l1 * (lx.l0 * v10[e] + lx.l1 * v11[e]);
+        st8x<T>(y, (orow + ox) * y_ld + coff + v * 8, 0, o);
+      }
+      coff += s.C;
+    }
   }
 }
 
@@ -469,7 +475,10 @@ extern "C" int pf_resize_concat(const void* const* xs, const int* lds, const int
     s[i] = ResizeSrc{xs[i], lds[i], Hs[i], Ws[i], Cs[i], ac_scale(Hs[i], OH), ac_scale(Ws[i], OW)};
     cv += Cs[i] / 8;
   }
-  LAUNCH_ROWS(resize_concat_kernel, B * OH, OW * (int)cv, s[0], s[1], s[2], nsrc, B, y, y_ld, OH, OW);
+  int cvmax = 0;
+  for (int i = 0; i < nsrc; ++i) cvmax = Cs[i] / 8 > cvmax ? Cs[i] / 8 : cvmax;
+  (void)cv;
+  LAUNCH_ROWS(resize_concat_kernel, B * OH, OW * cvmax, s[0], s[1], s[2], nsrc, B, y, y_ld, OH, OW);
   return ok();
 }
 

@@ -130,10 +130,23 @@ int pf_pack_fusion_input(const float* cdepth, const float* fdepth, const float* 
 int pf_nhwc_to_nchw_f32(const void* x, int x_ld, float* y, int B, int H, int W, int C, int in_f32, int dtype, void* stream);
 
 /* ---- metric-bins head ----------------------------------------------------------------------------- */
-/* AttractorLayerUnnormed (attractor.py:164-208, inv attractor alpha=300 gamma=2, kind='mean'):
- * c = bilinear_up(b_prev); out = c + mean_a( (A_a - c) / (1 + 300 (A_a - c)^2) ).  All float. */
-int pf_attractor(const float* A, int a_ld, int n_attr, const float* b_prev, int hp, int wp, float* out, int B, int h,
-                 int w, int n_bins, void* stream);
+/* AttractorLayerUnnormed (attractor.py:164-208) and the bounded AttractorLayer (:60-136) -- bin_centers_type, zoedepth_v1.py:90-104:
+ * c = bilinear_up(b_prev); out = c + reduce_a dist(A_a - c), A_a = A[a * a_stride] + a_eps.
+ *   attractor_exp 0: inv_attractor dx / (1 + 300 dx^2) (:44-57), 1: exp_attractor exp(-300 dx^2) dx (:29-41) -- alpha = 300, gamma = 2
+ *   are the jit functions' DEFAULTS: the layers call dist() without their own alpha / gamma, the config values never arrive;
+ *   kind_sum 0: mean over the attractors, 1: sum;
+ *   unnormed layer: A = softplus(mlp), a_stride 1, a_eps 0; bounded layer: A = relu(mlp) (2 n_attr channels), a_stride 2, a_eps 1e-3
+ *   (:105-106 overwrites the normalised pair with A[:, :, 0]).  All float. */
+int pf_attractor(const float* A, int a_ld, int n_attr, int a_stride, float a_eps, int attractor_exp, int kind_sum,
+                 const float* b_prev, int hp, int wp, float* out, int B, int h, int w, int n_bins, void* stream);
+/* Seed bin centres of the bounded variants: x [npix][x_ld] float = relu(mlp) (bounded) or softplus(mlp), out [npix][n_bins].
+ *   bounded   (SeedBinRegressor, localbins_layers.py:52-68): Bn = x + 1e-3; widths = (max - min) Bn / sum(Bn); edges = cumsum([min, widths]);
+ *             centre_k = (edge_k + edge_k+1) / 2
+ *   normalize (zoedepth_v1.py:178-182, 'normed' and 'hybrid2'): centre -> (centre - min) / (max - min) */
+int pf_seed_bin_centers(const float* x, int x_ld, float* out, long npix, int n_bins, float min_depth, float max_depth, int bounded,
+                        int normalize, void* stream);
+/* AttractorLayer tail (attractor.py:132-135): out = clip(sort_k((max - min) * b + min), min, max) per pixel; n_bins <= 64 */
+int pf_bounded_bin_centers(const float* b, float* out, long npix, int n_bins, float min_depth, float max_depth, void* stream);
 /* ConditionalLogBinomial tail + expectation (dist_layers.py:29-33,51-69,108-121, zoedepth_v1.py:215-219):
  * pt [B,h,w,4] float = softplus(mlp) ; centers [B,hc,wc,n_bins] float ; depth [B,h,w] float */
 int pf_logbinom_depth(const float* pt, int pt_ld, const float* centers, int hc, int wc, float* depth, int B, int h,
@@ -161,21 +174,24 @@ int pf_resize_bilinear_f32(const float* x, int H, int W, float* y, int OH, int O
  * `[:, :, ::-1]` of the 'u4k' raw-file branch (:24-25). dst is [3][OH][OW]. */
 int pf_u8_bicubic_to_f32(const uint8_t* src, int H, int W, int reverse_channels, float* dst, int OH, int OW, void* stream);
 
-/* estimator/utils/color.py:127-128: np.percentile(value[mask], q0 / q1) with mask = (value != invalid_val) when
- * use_invalid.  Exact order statistics by a three-level radix select on order-preserving integer keys, linear
+/* estimator/utils/color.py:121-128: np.percentile(value[mask], q0 / q1) with mask = (value != invalid_val) when
+ * use_invalid, or mask = (invalid_mask[i] == 0) when invalid_mask (n bytes, device) is not NULL -- an explicit mask REPLACES
+ * the value test, as in the reference.  Exact order statistics by a three-level radix select on order-preserving integer keys, linear
  * interpolation as numpy 1.24 (the reference's pinned version): index and weight in double, difference in float32.
  * out2 = {percentile q0, percentile q1} (device, float32; NaN when no valid sample).  `workspace`: device buffer of
  * pf_percentile_workspace_bytes() bytes, contents irrelevant on entry. */
 int pf_percentile_workspace_bytes(void);
-int pf_percentiles_f32(const float* x, long n, float invalid_val, int use_invalid, double q0, double q1, float* out2,
-                       void* workspace, void* stream);
+int pf_percentiles_f32(const float* x, long n, float invalid_val, int use_invalid, const uint8_t* invalid_mask, double q0, double q1,
+                       float* out2, void* workspace, void* stream);
 
 /* estimator/utils/color.py:130-150 + matplotlib Colormap.__call__(bytes=True): x = (v - vmin)/(vmax - vmin) in float32
  * (v*0 when vmin == vmax), index = trunc(x*N) with matplotlib's under / over / bad rules; lut_rgba has N+3 RGBA rows
  * (N colours, under, over, bad), already `(lut*255).astype(uint8)`; vmin_vmax is a device float[2] (e.g. the output of
- * pf_percentiles_f32); invalid pixels (v == invalid_val) get background_rgba (R | G<<8 | B<<16 | A<<24). out: [n][4]. */
+ * pf_percentiles_f32); invalid pixels (v == invalid_val, or invalid_mask[i] != 0 when the mask is not NULL) get
+ * background_rgba (R | G<<8 | B<<16 | A<<24). out: [n][4].  gamma_corrected (color.py:86-91) is a per-byte map, so the host
+ * applies it to the 1 KiB table and the background colour instead of to the image. */
 int pf_colorize_f32(const float* depth, long n, const float* vmin_vmax, const uint8_t* lut_rgba, int N, float invalid_val,
-                    int use_invalid, uint32_t background_rgba, uint8_t* out_rgba, void* stream);
+                    int use_invalid, const uint8_t* invalid_mask, uint32_t background_rgba, uint8_t* out_rgba, void* stream);
 
 /* estimator/tester/tester.py:75: (depth * 256).astype('uint16') (float32 product, truncation; clamped to [0, 65535]) */
 int pf_depth_to_u16(const float* depth, long n, float scale, uint16_t* out, void* stream);
@@ -184,11 +200,13 @@ int pf_depth_to_u16(const float* depth, long n, float scale, uint16_t* out, void
  * reduction over the ground-truth grid [H][W]: pred [ph][pw] is resized on the fly (bilinear, align_corners=False)
  * when the grids differ, clamped to [min_depth, max_depth] (inf -> max, nan -> min); mask = min < gt < max inside the
  * evaluation rectangle rows [crop_y0, crop_y1) x cols [crop_x0, crop_x1) (garg / eigen crops; whole image = 0,H,0,W);
- * edges (or NULL) = disp_gt_edges, non-zero = boundary pixel.  Terms in float32 like numpy, sums in double:
+ * edges (or NULL) = disp_gt_edges, non-zero = boundary pixel; additional_mask (or NULL) = [H][W] bytes, zero = excluded
+ * (metric.py:128-130, prompt-depth evaluation).  Terms in float32 like numpy, sums in double:
  * out13 = n, #(thresh<1.25), #(<1.25^2), #(<1.25^3), S|gt-p|/gt, S(gt-p)^2/gt, S(gt-p)^2, S(ln gt - ln p)^2,
  *         S(ln p - ln gt), S(ln p - ln gt)^2, S|log10 gt - log10 p|, S soft-edge error, #(mask & edges)   (device) */
-int pf_depth_metrics(const float* gt, int H, int W, const float* pred, int ph, int pw, const float* edges, float min_depth,
-                     float max_depth, int crop_y0, int crop_y1, int crop_x0, int crop_x1, double* out13, void* stream);
+int pf_depth_metrics(const float* gt, int H, int W, const float* pred, int ph, int pw, const float* edges,
+                     const uint8_t* additional_mask, float min_depth, float max_depth, int crop_y0, int crop_y1, int crop_x0, int crop_x1,
+                     double* out13, void* stream);
 
 /* SILogLoss forward value (estimator/models/losses.py:15-62), the loss of PatchFusion.forward(mode='train') (patchfusion.py:395):
  * pred / target float32 [n] of equal size; ws3 = 3 doubles of device scratch; *loss (device float) = 10*sqrt(var(g) + beta*mean(g)^2)

@@ -88,12 +88,14 @@ def colormap_bytes(x, lut, N):
     return lut[xa]
 
 
-def colorize(value, vmin=None, vmax=None, cmap="turbo_r", invalid_val=-99, background_color=(128, 128, 128, 255), vminp=2,
-             vmaxp=95):
-    """estimator/utils/color.py:95-150 (gamma_corrected=False, value_transform=None, invalid_mask=None) -> (H, W, 4) uint8.
+def colorize(value, vmin=None, vmax=None, cmap="turbo_r", invalid_val=-99, invalid_mask=None, background_color=(128, 128, 128, 255),
+             gamma_corrected=False, value_transform=None, vminp=2, vmaxp=95):
+    """estimator/utils/color.py:95-150 -> (H, W, 4) uint8.
     tester.py:68-71 calls it with cmap 'magma_r' / 'gray_r' and takes [:, :, [2, 1, 0]]."""
     value = np.asarray(value, dtype=np.float32).squeeze().copy()
-    invalid_mask = value == invalid_val
+    if invalid_mask is None:                                        # :121-122
+        invalid_mask = value == invalid_val
+    invalid_mask = np.asarray(invalid_mask, dtype=bool)
     mask = np.logical_not(invalid_mask)
     vmin = percentile_linear(value[mask], vminp) if vmin is None else np.float32(vmin)
     vmax = percentile_linear(value[mask], vmaxp) if vmax is None else np.float32(vmax)
@@ -102,9 +104,16 @@ def colorize(value, vmin=None, vmax=None, cmap="turbo_r", invalid_val=-99, backg
     else:
         value = value * np.float32(0.)
     value[invalid_mask] = np.nan
+    if value_transform:                                             # :140-141
+        value = value_transform(value)
     lut, N = colormap_lut_bytes(cmap)
     img = colormap_bytes(value, lut, N)
     img[invalid_mask] = background_color
+    if gamma_corrected:                                             # :86-91 (all four channels, alpha included)
+        img = img / 255
+        img = np.power(img, 2.2)
+        img = img * 255
+        img = img.astype(np.uint8)
     return img
 
 
@@ -144,8 +153,8 @@ def soft_edge_error(pred, gt, radius=1):
 
 
 def compute_metrics(gt, pred, min_depth_eval=0.1, max_depth_eval=10, disp_gt_edges=None, garg_crop=False, eigen_crop=False,
-                    dataset="nyu"):
-    """metric.py:87-148 (interpolate=True, additional_mask=None).  gt, pred: torch tensors [.., H, W] / [1, 1, h, w]."""
+                    dataset="nyu", additional_mask=None):
+    """metric.py:87-148 (interpolate=True).  gt, pred: torch tensors [.., H, W] / [1, 1, h, w]."""
     if gt.shape[-2:] != pred.shape[-2:]:
         pred = F.interpolate(pred, gt.shape[-2:], mode="bilinear", align_corners=False).squeeze()
     pred = pred.squeeze().cpu().numpy().copy()
@@ -162,6 +171,8 @@ def compute_metrics(gt, pred, min_depth_eval=0.1, max_depth_eval=10, disp_gt_edg
         y0, y1, x0, x1 = crop_rectangle(gh, gw, garg_crop, eigen_crop, dataset)
         eval_mask[y0:y1, x0:x1] = 1
     valid_mask = np.logical_and(valid_mask, eval_mask)
+    if additional_mask is not None:                                 # :128-130
+        valid_mask = np.logical_and(valid_mask, additional_mask.squeeze().detach().cpu().numpy())
     metrics = compute_errors(gt_depth[valid_mask], pred[valid_mask])
     if disp_gt_edges is not None:
         edges = disp_gt_edges.squeeze().numpy()

@@ -15,6 +15,9 @@ tools/test.py:122-123 fix_random_seed):
               2x2 tiles, cai_mode r4, process_num=4 (13 patches; SURVEY 8d "Config 1") and
               4x4 tiles, cai_mode m1, process_num=4 (16 patches; "Config 2"); 16384 sampled values each
               (`python -m oracle.make_golden cfg4k` regenerates only this file; ~5 CPU-minutes)
+  variants_vits: the tiny geometry with bin_centers_type / attractor_type / attractor_kind set to the values no shipped config
+              uses (patchfusion.py:132-146, attractor.py:112-129), weights seed 3, image seed 11: full m1 map + coarse depth each
+              (`python -m oracle.make_golden variants` regenerates only this file)
 """
 import os
 import random
@@ -69,11 +72,45 @@ def cfg4k():
     np.savez_compressed(os.path.join(OUT, "cfg4k_vits.npz"), **out)
 
 
+VARIANTS = (("normed", "inv", "mean"), ("hybrid1", "exp", "sum"), ("hybrid2", "inv", "sum"), ("softplus", "exp", "mean"))
+
+
+def variant_case(kind, atype, akind):
+    """config, synthetic weights and image of one variants_vits case (shared with the tests)"""
+    cfg = make_config("vits", (112, 154), (448, 616), (2, 2))
+    for b in ("coarse_branch", "fine_branch"):
+        cfg[b].update(bin_centers_type=kind, attractor_type=atype, attractor_kind=akind)
+    sd = synthetic_state_dict(patchfusion_spec(cfg), 3)
+    img = torch.rand(1, 3, 448, 616, generator=torch.Generator().manual_seed(11))
+    return cfg, sd, img
+
+
+def variants():
+    PF = ref_shim.import_reference()
+    out = {}
+    for kind, atype, akind in VARIANTS:
+        cfg, sd, img = variant_case(kind, atype, akind)
+        with ref_shim.in_reference_cwd():
+            m = PF(cfg).eval()
+        m.load_state_dict(sd, strict=True)
+        lr = m.resizer(img)
+        with torch.no_grad():
+            cd, _ = m.coarse_forward(lr)
+            d, _ = m(mode="infer", image_lr=lr, image_hr=img, cai_mode="m1", process_num=2)
+        out[f"{kind}_coarse_depth"] = cd[0, 0].numpy()
+        out[f"{kind}_depth_m1"] = d[0, 0].numpy()
+        print(kind, atype, akind, float(d.mean()), float(d.std()), float(d.min()), float(d.max()), flush=True)
+    np.savez_compressed(os.path.join(OUT, "variants_vits.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
     if len(sys.argv) > 1 and sys.argv[1] == "cfg4k":
         cfg4k()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "variants":
+        variants()
         return
     # ---------------- tiny ----------------
     m, cfg, img = build("vits", (112, 154), (448, 616), (2, 2))
@@ -111,6 +148,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "full_vits.npz"), **out)
     print("full_vits done", out["depth_m1_stats"])
     cfg4k()
+    variants()
 
 
 if __name__ == "__main__":

@@ -57,6 +57,17 @@ def main():
     out["depth"] = d
     for cmap in ("magma_r", "gray_r"):
         out[f"colorize_{cmap}"] = colorize(torch.from_numpy(d)[None, None], cmap=cmap)
+    # the optional arguments (color.py:121-122 invalid_mask, :140-141 value_transform, :86-91 gamma_corrected)
+    im = np.zeros(d.shape, bool)
+    im[20:50, 30:90] = True
+    im[np.random.RandomState(6).rand(*d.shape) < 0.02] = True
+    out["invalid_mask"] = im
+    out["np_percentiles_mask"] = np.array([np.percentile(d[~im], 2), np.percentile(d[~im], 95)], dtype=np.float64)
+    out["colorize_mask"] = colorize(torch.from_numpy(d)[None, None], cmap="magma_r", invalid_mask=im.copy())
+    out["colorize_gamma"] = colorize(torch.from_numpy(d)[None, None], cmap="magma_r", gamma_corrected=True)
+    out["colorize_transform"] = colorize(torch.from_numpy(d)[None, None], cmap="gray_r", value_transform=np.square)
+    out["colorize_all"] = colorize(torch.from_numpy(d)[None, None], cmap="turbo_r", invalid_mask=im.copy(), gamma_corrected=True,
+                                   value_transform=np.square, background_color=(10, 200, 30, 255))
     m = d != -99
     out["np_percentiles"] = np.array([np.percentile(d[m], 2), np.percentile(d[m], 95)], dtype=np.float64)
     out["uint16"] = (torch.from_numpy(np.abs(d))[None, None].clone().squeeze().detach().cpu().numpy() * 256).astype("uint16")
@@ -80,6 +91,12 @@ def main():
                         garg_crop=True, eigen_crop=False, dataset="u4k")
     out["metrics_resize_garg"] = np.array([float(r[k]) for k in sorted(r.keys())], dtype=np.float64)
     out["metrics_resize_garg_keys"] = np.array(sorted(r.keys()))
+    am = np.random.RandomState(9).rand(120, 164) < 0.6            # additional_mask (metric.py:128-130)
+    out["additional_mask"] = am
+    r = compute_metrics(torch.from_numpy(gt)[None, None], torch.from_numpy(pred.copy())[None, None], disp_gt_edges=torch.from_numpy(edges)[None],
+                        min_depth_eval=1e-3, max_depth_eval=80, garg_crop=False, eigen_crop=False, dataset="u4k",
+                        additional_mask=torch.from_numpy(am)[None, None])
+    out["metrics_addmask"] = np.array([float(r[k]) for k in sorted(r.keys())], dtype=np.float64)
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, {k: getattr(v, "shape", None) for k, v in out.items()})
 

@@ -165,16 +165,49 @@ def mlp1x1(sd, name, x, act_out=None):
     return x
 
 
-def attractor_unnormed(sd, name, x, b_prev, prev_emb, n_attr):
-    """attractor.py:164-208 AttractorLayerUnnormed.forward.  NOTE attractor.py:194-195 calls
-    ``dist(...)`` WITHOUT alpha/gamma, so inv_attractor's defaults alpha=300, gamma=2 are used
-    (config attractor_alpha=1000 is ignored); kind='mean' divides by n_attractors."""
+def _attractor_delta(A, b_c, bcfg):
+    """attractor.py:112-129 / :190-207: dist(A_i - c_j) reduced over the attractors.  NOTE both layers call ``dist(...)`` WITHOUT
+    alpha/gamma, so the jit functions' defaults alpha=300, gamma=2 apply (config attractor_alpha=1000 / attractor_gamma are
+    ignored); attractor_type 'exp' -> exp_attractor (:29-41), anything else -> inv_attractor (:44-57); kind 'mean' | 'sum'."""
+    dx = A.unsqueeze(2) - b_c.unsqueeze(1)
+    if bcfg.get("attractor_type", "inv") == "exp":
+        d = torch.exp(-300.0 * (torch.abs(dx) ** 2)) * dx
+    else:
+        d = dx / (1 + 300.0 * dx.pow(2))
+    return {"mean": torch.mean, "sum": torch.sum}[bcfg.get("attractor_kind", "mean")](d, dim=1)
+
+
+def attractor_unnormed(sd, name, x, b_prev, prev_emb, bcfg):
+    """attractor.py:164-208 AttractorLayerUnnormed.forward -> (b_new_centers, B_centers) (the same tensor)."""
     x = x + up(prev_emb, x.shape[-2:])
     A = mlp1x1(sd, name, x, "softplus")                                   # [B, n_attr, h, w]
     b_c = up(b_prev, A.shape[-2:])                                        # [B, n_bins, h, w]
-    dx = A.unsqueeze(2) - b_c.unsqueeze(1)
-    delta = (dx / (1 + 300.0 * dx.pow(2))).mean(dim=1)
-    return b_c + delta
+    b_new = b_c + _attractor_delta(A, b_c, bcfg)
+    return b_new, b_new
+
+
+def attractor_normed(sd, name, x, b_prev, prev_emb, bcfg, min_depth, max_depth):
+    """attractor.py:60-136 AttractorLayer.forward (bounded centres).  NOTE :105-106: the linear normalisation A / A.sum(dim=2)
+    is computed and then OVERWRITTEN by A[:, :, 0] -- the attractor points are the even output channels of the MLP
+    (ReLU + 1e-3), unnormalised.  Returns (b_new_centers normed, B_centers = clip(sort(scale(b_new))))."""
+    x = x + up(prev_emb, x.shape[-2:])
+    A = F.relu(mlp1x1(sd, name, x)) + 1e-3                                # [B, 2*n_attr, h, w]
+    n, c, h, w = A.shape
+    A = A.view(n, c // 2, 2, h, w)[:, :, 0]
+    b_c = up(b_prev, (h, w))
+    b_new = b_c + _attractor_delta(A, b_c, bcfg)
+    Bc = (max_depth - min_depth) * b_new + min_depth
+    Bc, _ = torch.sort(Bc, dim=1)
+    return b_new, torch.clip(Bc, min_depth, max_depth)
+
+
+def seed_bins_normed(sd, name, x, min_depth, max_depth):
+    """localbins_layers.py:29-68 SeedBinRegressor.forward -> B_centers (bounded on (min_depth, max_depth))."""
+    Bn = F.relu(mlp1x1(sd, name, x)) + 1e-3
+    widths = (max_depth - min_depth) * (Bn / Bn.sum(dim=1, keepdim=True))
+    widths = F.pad(widths, (0, 0, 0, 0, 1, 0), mode="constant", value=min_depth)
+    edges = torch.cumsum(widths, dim=1)
+    return 0.5 * (edges[:, :-1] + edges[:, 1:])
 
 
 def log_binomial_depth(sd, p, last, emb, centers, min_temp, max_temp, n_bins=64, taps=None):
@@ -204,22 +237,37 @@ def log_binomial_depth(sd, p, last, emb, centers, min_temp, max_temp, n_bins=64,
     return torch.sum(probs * centers, dim=1, keepdim=True)
 
 
-def bins_head(sd, p, x0, x_blocks, last, rel_cond, bcfg, taps=None):
-    """zoedepth_v1.py:173-219 == patchfusion.py:297-340 (same math, different weights / inputs)."""
-    n_attr = bcfg["n_attractors"]
-    b_prev = mlp1x1(sd, p + "seed_bin_regressor", x0, "softplus")
+def bins_head(sd, p, x0, x_blocks, last, rel_cond, bcfg, taps=None, min_depth=None, max_depth=None):
+    """zoedepth_v1.py:173-219 == patchfusion.py:297-340 (same math, different weights / inputs).  bin_centers_type
+    (zoedepth_v1.py:90-104 == patchfusion.py:132-146): 'softplus' (all shipped configs) | 'normed' | 'hybrid1' | 'hybrid2' picks the
+    seed regressor and the attractor layer; min_depth / max_depth only matter for the bounded variants (default: the branch
+    config's own)."""
+    kind = bcfg.get("bin_centers_type", "softplus")
+    if kind not in ("normed", "softplus", "hybrid1", "hybrid2"):
+        raise ValueError("bin_centers_type should be one of 'normed', 'softplus', 'hybrid1', 'hybrid2'")
+    lo = float(bcfg.get("min_depth", 1e-3) if min_depth is None else min_depth)
+    hi = float(bcfg.get("max_depth", 10) if max_depth is None else max_depth)
+    if kind in ("normed", "hybrid1"):
+        b_prev = seed_bins_normed(sd, p + "seed_bin_regressor", x0, lo, hi)
+    else:
+        b_prev = mlp1x1(sd, p + "seed_bin_regressor", x0, "softplus")
+    if kind in ("normed", "hybrid2"):                                      # zoedepth_v1.py:178-182
+        b_prev = (b_prev - lo) / (hi - lo)
     prev_emb = mlp1x1(sd, p + "seed_projector", x0)
-    emb = None
+    emb = centers = None
     for i, xb in enumerate(x_blocks):
         emb = mlp1x1(sd, f"{p}projectors.{i}", xb)
-        b_prev = attractor_unnormed(sd, f"{p}attractors.{i}", emb, b_prev, prev_emb, n_attr[i])
+        if kind in ("normed", "hybrid2"):
+            b_prev, centers = attractor_normed(sd, f"{p}attractors.{i}", emb, b_prev, prev_emb, bcfg, lo, hi)
+        else:
+            b_prev, centers = attractor_unnormed(sd, f"{p}attractors.{i}", emb, b_prev, prev_emb, bcfg)
         prev_emb = emb
         if taps is not None:
             taps[f"bins_centers{i}"] = b_prev
     rel_cond = up(rel_cond, last.shape[2:])
     last = torch.cat([last, rel_cond], dim=1)
     emb = up(emb, last.shape[-2:])
-    return log_binomial_depth(sd, p, last, emb, b_prev, bcfg["min_temp"], bcfg["max_temp"], bcfg["n_bins"], taps)
+    return log_binomial_depth(sd, p, last, emb, centers, bcfg["min_temp"], bcfg["max_temp"], bcfg["n_bins"], taps)
 
 
 def branch_forward(sd, p, x, bcfg, taps=None):
@@ -396,7 +444,8 @@ def fusion_forward(sd, cfg, fine_depth, crops, coarse_feats, fine_feats, bbox, c
                                   g2l_cache=g2l_cache, taps=taps)
     last = fused[-1]
     rel_cond = torch.zeros((last.shape[0], 1) + tuple(last.shape[-2:]), device=last.device)
-    return bins_head(sd, "", fused[0], fused[1:-1], last, rel_cond, cfg["coarse_branch"], None)
+    return bins_head(sd, "", fused[0], fused[1:-1], last, rel_cond, cfg["coarse_branch"], None,
+                     min_depth=cfg["min_depth"], max_depth=cfg["max_depth"])       # patchfusion.py:152-163: config.min/max_depth
 
 
 def silog_loss(pred, target, min_depth, max_depth, beta=0.15):

@@ -46,7 +46,9 @@ SIGNATURES = {
     "pf_copy_channels": [vp, ci, vp, ci, cl, ci, ci, ci, ci, vp],
     "pf_pack_fusion_input": [vp, vp, vp, vp, ci, ci, ci, ci, vp],
     "pf_nhwc_to_nchw_f32": [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp],
-    "pf_attractor": [vp, ci, ci, vp, ci, ci, vp, ci, ci, ci, ci, vp],
+    "pf_attractor": [vp, ci, ci, ci, cf, ci, ci, vp, ci, ci, vp, ci, ci, ci, ci, vp],
+    "pf_seed_bin_centers": [vp, ci, vp, cl, ci, cf, cf, ci, ci, vp],
+    "pf_bounded_bin_centers": [vp, vp, cl, ci, cf, cf, vp],
     "pf_logbinom_depth": [vp, ci, vp, ci, ci, vp, ci, ci, ci, ci, cf, cf, vp],
     "pf_stitch_init": [vp, vp, ci, ci, vp, vp, vp, ci, ci, ci, vp],
     "pf_stitch_finish_init": [vp, vp, vp, cl, vp],
@@ -55,11 +57,11 @@ SIGNATURES = {
     "pf_resize_bilinear_f32": [vp, ci, ci, vp, ci, ci, vp],
     # input / output side (io.hip)
     "pf_u8_bicubic_to_f32": [vp, ci, ci, ci, vp, ci, ci, vp],
-    "pf_percentiles_f32": [vp, cl, cf, ci, C.c_double, C.c_double, vp, vp, vp],
-    "pf_colorize_f32": [vp, cl, vp, vp, ci, cf, ci, C.c_uint32, vp, vp],
+    "pf_percentiles_f32": [vp, cl, cf, ci, vp, C.c_double, C.c_double, vp, vp, vp],
+    "pf_colorize_f32": [vp, cl, vp, vp, ci, cf, ci, vp, C.c_uint32, vp, vp],
     "pf_depth_to_u16": [vp, cl, cf, vp, vp],
     "pf_silog_loss": [vp, vp, cl, cf, cf, cf, vp, vp, vp],
-    "pf_depth_metrics": [vp, ci, ci, vp, ci, ci, vp, cf, cf, ci, ci, ci, ci, vp, vp],
+    "pf_depth_metrics": [vp, ci, ci, vp, ci, ci, vp, vp, cf, cf, ci, ci, ci, ci, vp, vp],
 }
 NON_STATUS = ("pf_last_error", "pf_version", "pf_percentile_workspace_bytes")   # entry points that do not return a status
 

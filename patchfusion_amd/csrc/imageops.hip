@@ -292,11 +292,16 @@ __global__ void nhwc_to_nchw_kernel(const void* __restrict__ x, int x_ld, float*
 // ---------------------------------------------------------------------------------------------
 // metric-bins head
 // ---------------------------------------------------------------------------------------------
-__global__ void attractor_kernel(const float* __restrict__ A, int a_ld, int n_attr, const float* __restrict__ bp, int hp, int wp,
-                                 float* __restrict__ out, int B, int h, int w, int n_bins, float sh, float sw) {
+// AttractorLayerUnnormed (attractor.py:164-208) and AttractorLayer (:60-136): c = bilinear_up(b_prev); out = c + reduce_a dist(A_a - c).
+// EXP = exp_attractor (:29-41) instead of inv_attractor (:44-57); both with the jit defaults alpha = 300, gamma = 2 because the layers
+// call dist() without their own alpha / gamma.  a_stride / a_eps: the bounded layer's attractor points are the EVEN MLP outputs
+// (ReLU + 1e-3; :105-106 overwrites the normalised pair with A[:, :, 0]).  scale = 1/n_attr (kind 'mean') or 1 (kind 'sum').
+template <bool EXP>
+__global__ void attractor_kernel(const float* __restrict__ A, int a_ld, int n_attr, int a_stride, float a_eps, float scale,
+                                 const float* __restrict__ bp, int hp, int wp, float* __restrict__ out, int B, int h, int w, int n_bins,
+                                 float sh, float sw) {
   const int bv = n_bins >> 2;
   const long total = (long)B * h * w * bv;
-  const float inv_n = 1.0f / (float)n_attr;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int v = (int)(i % bv);
     long pix = i / bv;
@@ -317,14 +322,61 @@ __global__ void attractor_kernel(const float* __restrict__ A, int a_ld, int n_at
     }
     const float* a = A + pix * a_ld;
     for (int k = 0; k < n_attr; ++k) {
-      const float ak = a[k];
+      const float ak = a[k * a_stride] + a_eps;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float dx = ak - c[e];
-        d[e] += dx / (1.0f + 300.0f * (dx * dx));
+        d[e] += EXP ? expf(-300.0f * (dx * dx)) * dx : dx / (1.0f + 300.0f * (dx * dx));
       }
     }
-    store4(out + pix * n_bins + v * 4, c[0] + d[0] * inv_n, c[1] + d[1] * inv_n, c[2] + d[2] * inv_n, c[3] + d[3] * inv_n);
+    store4(out + pix * n_bins + v * 4, c[0] + d[0] * scale, c[1] + d[1] * scale, c[2] + d[2] * scale, c[3] + d[3] * scale);
+  }
+}
+
+// SeedBinRegressor (localbins_layers.py:52-68, bounded seed centres) and the (x - min) / (max - min) of zoedepth_v1.py:178-182:
+//   bounded:   Bn = relu_out + 1e-3; width_k = (max - min) * Bn_k / sum(Bn); edges = cumsum([min, width...]); centre_k = (e_k + e_k+1) / 2
+//   normalize: centre -> (centre - min) / (max - min)
+// One thread per pixel, channels walked in order (torch.cumsum / sum over dim 1 accumulate in this order too).
+__global__ void seed_bin_centers_kernel(const float* __restrict__ x, int ld, float* __restrict__ out, long npix, int n_bins, float lo,
+                                        float hi, int bounded, int normalize) {
+  const float range = hi - lo;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+    const float* r = x + i * ld;
+    float* o = out + i * n_bins;
+    if (bounded) {
+      float sum = 0.f;
+      for (int k = 0; k < n_bins; ++k) sum += r[k] + 1e-3f;
+      float e0 = lo;
+      for (int k = 0; k < n_bins; ++k) {
+        const float e1 = e0 + range * ((r[k] + 1e-3f) / sum);
+        const float c = 0.5f * (e0 + e1);
+        o[k] = normalize ? (c - lo) / range : c;
+        e0 = e1;
+      }
+    } else {
+      for (int k = 0; k < n_bins; ++k) o[k] = normalize ? (r[k] - lo) / range : r[k];
+    }
+  }
+}
+
+// AttractorLayer tail (attractor.py:132-135): B_centers = clip(sort((max - min) * b + min)).  One wave per pixel, lane k = bin k
+// (n_bins <= 64, +inf padding), bitonic sort across the lanes.
+__global__ __launch_bounds__(256) void bounded_centers_kernel(const float* __restrict__ b, float* __restrict__ out, long npix, int n_bins,
+                                                              float lo, float hi) {
+  const int lane = threadIdx.x & 63;
+  const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  for (long i = wave; i < npix; i += nwaves) {
+    float v = lane < n_bins ? (hi - lo) * b[i * n_bins + lane] + lo : INFINITY;
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        const float o = __shfl_xor(v, j, 64);
+        const bool up = (lane & k) == 0, low = (lane & j) == 0;
+        v = (up == low) ? fminf(v, o) : fmaxf(v, o);
+      }
+    }
+    if (lane < n_bins) out[i * n_bins + lane] = fminf(fmaxf(v, lo), hi);
   }
 }
 
@@ -533,11 +585,32 @@ extern "C" int pf_nhwc_to_nchw_f32(const void* x, int x_ld, float* y, int B, int
   return ok();
 }
 
-extern "C" int pf_attractor(const float* A, int a_ld, int n_attr, const float* b_prev, int hp, int wp, float* out, int B, int h, int w,
-                            int n_bins, void* stream) {
-  if (!A || !b_prev || !out || n_bins % 4 || n_attr < 1) return PF_ERR_ARG;
+extern "C" int pf_attractor(const float* A, int a_ld, int n_attr, int a_stride, float a_eps, int attractor_exp, int kind_sum,
+                            const float* b_prev, int hp, int wp, float* out, int B, int h, int w, int n_bins, void* stream) {
+  if (!A || !b_prev || !out || n_bins % 4 || n_attr < 1 || a_stride < 1) return PF_ERR_ARG;
   const long total = (long)B * h * w * (n_bins / 4);
-  hipLaunchKernelGGL(attractor_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ST(stream), A, a_ld, n_attr, b_prev, hp, wp, out, B, h, w, n_bins, ac_scale(hp, h), ac_scale(wp, w));
+  const float scale = kind_sum ? 1.0f : 1.0f / (float)n_attr;
+  if (attractor_exp)
+    hipLaunchKernelGGL(attractor_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, ST(stream), A, a_ld, n_attr, a_stride, a_eps, scale,
+                       b_prev, hp, wp, out, B, h, w, n_bins, ac_scale(hp, h), ac_scale(wp, w));
+  else
+    hipLaunchKernelGGL(attractor_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, ST(stream), A, a_ld, n_attr, a_stride, a_eps, scale,
+                       b_prev, hp, wp, out, B, h, w, n_bins, ac_scale(hp, h), ac_scale(wp, w));
+  return ok();
+}
+
+extern "C" int pf_seed_bin_centers(const float* x, int x_ld, float* out, long npix, int n_bins, float min_depth, float max_depth,
+                                   int bounded, int normalize, void* stream) {
+  if (!x || !out || npix <= 0 || n_bins < 1 || x_ld < n_bins) return PF_ERR_ARG;
+  hipLaunchKernelGGL(seed_bin_centers_kernel, dim3(grid_for(npix, 64)), dim3(64), 0, ST(stream), x, x_ld, out, npix, n_bins, min_depth,
+                     max_depth, bounded, normalize);
+  return ok();
+}
+
+extern "C" int pf_bounded_bin_centers(const float* b, float* out, long npix, int n_bins, float min_depth, float max_depth, void* stream) {
+  if (!b || !out || npix <= 0 || n_bins < 1 || n_bins > 64) return PF_ERR_ARG;
+  hipLaunchKernelGGL(bounded_centers_kernel, dim3(grid_for(npix * 64, 256)), dim3(256), 0, ST(stream), b, out, npix, n_bins, min_depth,
+                     max_depth);
   return ok();
 }
 

@@ -137,7 +137,8 @@ __global__ void pct_init_kernel(PctWs* ws) {
 }
 
 template <int LEVEL>
-__global__ __launch_bounds__(256) void pct_hist_kernel(const float* __restrict__ x, long n, float invalid, int use_invalid, PctWs* ws) {
+__global__ __launch_bounds__(256) void pct_hist_kernel(const float* __restrict__ x, long n, float invalid, int use_invalid,
+                                                       const uint8_t* __restrict__ imask, PctWs* ws) {
   constexpr int NH = LEVEL == 0 ? 1 : PCT_R;
   __shared__ unsigned int h[NH][PCT_BINS];
   for (int i = threadIdx.x; i < NH * PCT_BINS; i += blockDim.x) (&h[0][0])[i] = 0u;
@@ -147,14 +148,15 @@ __global__ __launch_bounds__(256) void pct_hist_kernel(const float* __restrict__
   __syncthreads();
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float v = x[i];
-    if (LEVEL != 0 && use_invalid && v == invalid) continue;
+    const bool inval = imask ? imask[i] != 0 : (use_invalid && v == invalid);   // color.py:121-122: an explicit mask replaces the value test
+    if (LEVEL != 0 && inval) continue;
     const unsigned int k = f2key(v);
     if (LEVEL == 0) {
       // depth maps put most pixels into a handful of (sign, exponent) bins: 64 lanes hammering one LDS counter
       // serialize.  Peel the (up to 8) most common bins of the wave with ballots - one atomic per bin - and let
       // the stragglers add individually.
       const unsigned int bin = k >> 21;
-      bool pending = !(use_invalid && v == invalid);
+      bool pending = !inval;
 #pragma unroll 1
       for (int it = 0; it < 8; ++it) {
         const unsigned long long live = __ballot(pending);
@@ -267,13 +269,13 @@ __global__ __launch_bounds__(256) void pct_select_kernel(PctWs* ws, double q0, d
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void colorize_kernel(const float* __restrict__ depth, long n, const float* __restrict__ vmm,
                                                        const uint32_t* __restrict__ lut, int N, float invalid, int use_invalid,
-                                                       uint32_t background, uint32_t* __restrict__ out) {
+                                                       const uint8_t* __restrict__ imask, uint32_t background, uint32_t* __restrict__ out) {
   const float vmin = vmm[0], vmax = vmm[1];
   const float den = vmax - vmin;
   const float fN = (float)N;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float v = depth[i];
-    if (use_invalid && v == invalid) {
+    if (imask ? imask[i] != 0 : (use_invalid && v == invalid)) {
       out[i] = background;
       continue;
     }
@@ -333,8 +335,9 @@ __device__ __forceinline__ float pred_at(const float* __restrict__ pred, int ph,
 }
 
 __global__ __launch_bounds__(256) void depth_metrics_kernel(const float* __restrict__ gt, int H, int W, const float* __restrict__ pred,
-                                                            int ph, int pw, const float* __restrict__ edges, float lo, float hi,
-                                                            int cy0, int cy1, int cx0, int cx1, double* __restrict__ out) {
+                                                            int ph, int pw, const float* __restrict__ edges,
+                                                            const uint8_t* __restrict__ extra, float lo, float hi, int cy0, int cy1, int cx0,
+                                                            int cx1, double* __restrict__ out) {
   double s[MET_N];
 #pragma unroll
   for (int k = 0; k < MET_N; ++k) s[k] = 0.0;
@@ -344,6 +347,7 @@ __global__ __launch_bounds__(256) void depth_metrics_kernel(const float* __restr
     const int y = (int)(i / W), x = (int)(i - (long)y * W);
     const float g = gt[i];
     if (!(g > lo && g < hi) || y < cy0 || y >= cy1 || x < cx0 || x >= cx1) continue;
+    if (extra && extra[i] == 0) continue;                 // metric.py:128-130 additional_mask (prompt-depth evaluation)
     const float p = pred_at(pred, ph, pw, H, W, y, x, sy, sx, lo, hi);
     const float th = fmaxf(g / p, p / g);
     const float d = g - p;
@@ -447,28 +451,28 @@ extern "C" int pf_u8_bicubic_to_f32(const uint8_t* src, int H, int W, int revers
 
 extern "C" int pf_percentile_workspace_bytes(void) { return (int)sizeof(PctWs); }
 
-extern "C" int pf_percentiles_f32(const float* x, long n, float invalid_val, int use_invalid, double q0, double q1, float* out2,
-                                  void* workspace, void* stream) {
+extern "C" int pf_percentiles_f32(const float* x, long n, float invalid_val, int use_invalid, const uint8_t* invalid_mask, double q0,
+                                  double q1, float* out2, void* workspace, void* stream) {
   if (!x || !out2 || !workspace || n <= 0) return PF_ERR_ARG;
   if (!(q0 >= 0.0 && q0 <= 100.0 && q1 >= 0.0 && q1 <= 100.0)) return PF_ERR_ARG;
   PctWs* ws = reinterpret_cast<PctWs*>(workspace);
   hipStream_t st = ST(stream);
   const int g = grid_for(n, 256 * 8);
   hipLaunchKernelGGL(pct_init_kernel, dim3(8), dim3(256), 0, st, ws);
-  hipLaunchKernelGGL(pct_hist_kernel<0>, dim3(g), dim3(256), 0, st, x, n, invalid_val, use_invalid, ws);
+  hipLaunchKernelGGL(pct_hist_kernel<0>, dim3(g), dim3(256), 0, st, x, n, invalid_val, use_invalid, invalid_mask, ws);
   hipLaunchKernelGGL(pct_select_kernel<0>, dim3(1), dim3(256), 0, st, ws, q0, q1, out2);
-  hipLaunchKernelGGL(pct_hist_kernel<1>, dim3(g), dim3(256), 0, st, x, n, invalid_val, use_invalid, ws);
+  hipLaunchKernelGGL(pct_hist_kernel<1>, dim3(g), dim3(256), 0, st, x, n, invalid_val, use_invalid, invalid_mask, ws);
   hipLaunchKernelGGL(pct_select_kernel<1>, dim3(1), dim3(256), 0, st, ws, q0, q1, out2);
-  hipLaunchKernelGGL(pct_hist_kernel<2>, dim3(g), dim3(256), 0, st, x, n, invalid_val, use_invalid, ws);
+  hipLaunchKernelGGL(pct_hist_kernel<2>, dim3(g), dim3(256), 0, st, x, n, invalid_val, use_invalid, invalid_mask, ws);
   hipLaunchKernelGGL(pct_select_kernel<2>, dim3(1), dim3(256), 0, st, ws, q0, q1, out2);
   return ok();
 }
 
 extern "C" int pf_colorize_f32(const float* depth, long n, const float* vmin_vmax, const uint8_t* lut_rgba, int N, float invalid_val,
-                               int use_invalid, uint32_t background_rgba, uint8_t* out_rgba, void* stream) {
+                               int use_invalid, const uint8_t* invalid_mask, uint32_t background_rgba, uint8_t* out_rgba, void* stream) {
   if (!depth || !vmin_vmax || !lut_rgba || !out_rgba || n <= 0 || N <= 0) return PF_ERR_ARG;
   hipLaunchKernelGGL(colorize_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ST(stream), depth, n, vmin_vmax,
-                     reinterpret_cast<const uint32_t*>(lut_rgba), N, invalid_val, use_invalid, background_rgba,
+                     reinterpret_cast<const uint32_t*>(lut_rgba), N, invalid_val, use_invalid, invalid_mask, background_rgba,
                      reinterpret_cast<uint32_t*>(out_rgba));
   return ok();
 }
@@ -479,12 +483,13 @@ extern "C" int pf_depth_to_u16(const float* depth, long n, float scale, uint16_t
   return ok();
 }
 
-extern "C" int pf_depth_metrics(const float* gt, int H, int W, const float* pred, int ph, int pw, const float* edges, float min_depth,
-                                float max_depth, int crop_y0, int crop_y1, int crop_x0, int crop_x1, double* out13, void* stream) {
+extern "C" int pf_depth_metrics(const float* gt, int H, int W, const float* pred, int ph, int pw, const float* edges,
+                                const uint8_t* additional_mask, float min_depth, float max_depth, int crop_y0, int crop_y1, int crop_x0,
+                                int crop_x1, double* out13, void* stream) {
   if (!gt || !pred || !out13 || H <= 0 || W <= 0 || ph <= 0 || pw <= 0) return PF_ERR_ARG;
   hipLaunchKernelGGL(zero_f64_kernel, dim3(1), dim3(64), 0, ST(stream), out13, MET_N);
   hipLaunchKernelGGL(depth_metrics_kernel, dim3(grid_for((long)H * W, 256)), dim3(256), 0, ST(stream), gt, H, W, pred, ph, pw, edges,
-                     min_depth, max_depth, crop_y0, crop_y1, crop_x0, crop_x1, out13);
+                     additional_mask, min_depth, max_depth, crop_y0, crop_y1, crop_x0, crop_x1, out13);
   return ok();
 }
 

@@ -32,8 +32,20 @@ def _g(sd, name, device):
 class BinsHead:
     """seed regressor/projector, 4 x (projector, attractor), conditional log-binomial, expectation."""
 
-    def __init__(self, sd, prefix, C, bcfg, dtype, device, with_rel):
+    def __init__(self, sd, prefix, C, bcfg, dtype, device, with_rel, min_depth=None, max_depth=None):
         self.dtype, self.device = dtype, device
+        # bin_centers_type (zoedepth_v1.py:90-104 == patchfusion.py:132-146): bounded seed regressor for 'normed' / 'hybrid1', bounded
+        # attractor layer for 'normed' / 'hybrid2'; min / max depth only matter for those (branch head: the branch config's own,
+        # fusion head: the top-level config's, patchfusion.py:152-163)
+        kind = bcfg.get("bin_centers_type", "softplus")
+        if kind not in ("normed", "softplus", "hybrid1", "hybrid2"):
+            raise ValueError("bin_centers_type should be one of 'normed', 'softplus', 'hybrid1', 'hybrid2'")
+        self.seed_bounded, self.attr_bounded = kind in ("normed", "hybrid1"), kind in ("normed", "hybrid2")
+        self.lo = float(bcfg.get("min_depth", 1e-3) if min_depth is None else min_depth)
+        self.hi = float(bcfg.get("max_depth", 10) if max_depth is None else max_depth)
+        self.attr_type, self.attr_kind = bcfg.get("attractor_type", "inv"), bcfg.get("attractor_kind", "mean")
+        if self.attr_kind not in ("mean", "sum"):
+            raise KeyError(self.attr_kind)                          # attractor.py:118 indexes a dict with it
         self.n_attr = list(bcfg["n_attractors"])
         self.n_bins = int(bcfg["n_bins"])
         self.emb = int(bcfg["bin_embedding_dim"])
@@ -68,7 +80,10 @@ class BinsHead:
         t = ops.empty((B, h0, w0, self.sbr0.cout), dt, dev)
         ops.conv(x0, self.sbr0, t, act="relu")
         b_prev = ops.empty((B, h0, w0, self.n_bins), F32, dev)
-        ops.conv(t, self.sbr2, b_prev, act="softplus")
+        ops.conv(t, self.sbr2, b_prev, act="relu" if self.seed_bounded else "softplus")
+        if self.seed_bounded or self.attr_bounded:                  # localbins_layers.py:52-68, zoedepth_v1.py:178-182
+            b_prev = ops.seed_bin_centers(b_prev, ops.empty((B, h0, w0, self.n_bins), F32, dev), self.lo, self.hi,
+                                          bounded=self.seed_bounded, normalize=self.attr_bounded)
         t = ops.empty((B, h0, w0, self.sp0.cout), dt, dev)
         ops.conv(x0, self.sp0, t, act="relu")
         prev_emb = ops.empty((B, h0, w0, self.emb), dt, dev)
@@ -87,9 +102,12 @@ class BinsHead:
             t = ops.empty((B, h, w, a0.cout), dt, dev)
             ops.conv(xs, a0, t, act="relu")
             A = ops.empty((B, h, w, a2.cout), F32, dev)
-            ops.conv(t, a2, A, act="softplus")
+            ops.conv(t, a2, A, act="relu" if self.attr_bounded else "softplus")
             b_new = ops.empty((B, h, w, self.n_bins), F32, dev)
-            ops.attractor(A, self.n_attr[i], b_prev, b_new)
+            if self.attr_bounded:                                   # attractor.py:100-106: even channels, ReLU + 1e-3
+                ops.attractor(A, self.n_attr[i], b_prev, b_new, a_stride=2, a_eps=1e-3, attractor_type=self.attr_type, kind=self.attr_kind)
+            else:
+                ops.attractor(A, self.n_attr[i], b_prev, b_new, attractor_type=self.attr_type, kind=self.attr_kind)
             b_prev, prev_emb = b_new, emb
             if taps is not None:
                 taps[f"bins_centers{i}"] = b_new
@@ -100,6 +118,8 @@ class BinsHead:
         pt = ops.empty((B, H, W, self.mlp2.cout), F32, dev)
         ops.conv(t, self.mlp2, pt, act="softplus")
         depth = ops.empty((B, H, W), F32, dev)
+        if self.attr_bounded:                                       # attractor.py:132-135: the last layer's scaled, sorted, clipped centres
+            b_prev = ops.bounded_bin_centers(b_prev, ops.empty(tuple(b_prev.shape), F32, dev), self.lo, self.hi)
         ops.logbinom_depth(pt, b_prev, depth, self.min_temp, self.max_temp)
         return depth
 
@@ -398,7 +418,8 @@ class FusionNet:
         self.down = [dcbn(f"{g}down_conv_list.{i}.maxpool_conv.1") for i in range(5)]
         self.upc = [dcwobn(f"{g}up_conv_list.{i}.conv") for i in range(5)]
         self.convs = [dcwobn(f"{g}convs.{i}") for i in range(6)]
-        self.head = BinsHead(sd, "", self.C, cfg["coarse_branch"], dtype, device, with_rel=False)
+        self.head = BinsHead(sd, "", self.C, cfg["coarse_branch"], dtype, device, with_rel=False,
+                             min_depth=cfg["min_depth"], max_depth=cfg["max_depth"])
 
     def forward(self, ops, crops, rois, fine_depth, fine_feats, coarse_depth, coarse_feats, g2l, taps=None):
         """crops [B,3,H,W] f32; rois f32 [B,5] (batch index 0, box in process coordinates);

@@ -267,12 +267,30 @@ class HipOps:
 
     # ---------------- metric-bins head ----------------
     @staticmethod
-    def attractor(A, n_attr, b_prev, out):
-        """A [B,h,w,>=n_attr] f32 ; b_prev [B,hp,wp,n_bins] f32 ; out [B,h,w,n_bins] f32"""
+    def attractor(A, n_attr, b_prev, out, a_stride=1, a_eps=0.0, attractor_type="inv", kind="mean"):
+        """A [B,h,w,>=n_attr*a_stride] f32 ; b_prev [B,hp,wp,n_bins] f32 ; out [B,h,w,n_bins] f32 (include/pf_hip.h: pf_attractor)"""
         B, h, w, nb = out.shape
         _, hp, wp, _ = b_prev.shape
         assert A.dtype == b_prev.dtype == out.dtype == torch.float32 and b_prev.is_contiguous() and out.is_contiguous()
-        check(_L.pf_attractor(_p(A), _ld(A), n_attr, _p(b_prev), hp, wp, _p(out), B, h, w, nb, _stream()), "pf_attractor")
+        assert A.shape[-1] >= (n_attr - 1) * a_stride + 1 and kind in ("mean", "sum")
+        check(_L.pf_attractor(_p(A), _ld(A), n_attr, int(a_stride), float(a_eps), int(attractor_type == "exp"), int(kind == "sum"),
+                              _p(b_prev), hp, wp, _p(out), B, h, w, nb, _stream()), "pf_attractor")
+
+    @staticmethod
+    def seed_bin_centers(x, out, min_depth, max_depth, bounded, normalize):
+        """x [B,h,w,>=n_bins] f32 (relu / softplus MLP output) -> out [B,h,w,n_bins] f32 (include/pf_hip.h: pf_seed_bin_centers)"""
+        assert x.dtype == out.dtype == torch.float32 and out.is_contiguous() and x.shape[:3] == out.shape[:3]
+        check(_L.pf_seed_bin_centers(_p(x), _ld(x), _p(out), out.numel() // out.shape[-1], out.shape[-1], float(min_depth), float(max_depth),
+                                     int(bool(bounded)), int(bool(normalize)), _stream()), "pf_seed_bin_centers")
+        return out
+
+    @staticmethod
+    def bounded_bin_centers(b, out, min_depth, max_depth):
+        """attractor.py:132-135: out = clip(sort((max - min) * b + min)) along the bins; b, out [B,h,w,n_bins] f32 contiguous"""
+        assert b.dtype == out.dtype == torch.float32 and b.is_contiguous() and out.is_contiguous() and b.shape == out.shape
+        check(_L.pf_bounded_bin_centers(_p(b), _p(out), out.numel() // out.shape[-1], out.shape[-1], float(min_depth), float(max_depth),
+                                        _stream()), "pf_bounded_bin_centers")
+        return out
 
     @staticmethod
     def logbinom_depth(pt, centers, depth, min_temp, max_temp):
@@ -322,23 +340,29 @@ class HipOps:
         return out
 
     @staticmethod
-    def percentiles(x, q0, q1, invalid_val=None, out=None):
-        """Exact np.percentile(x[x != invalid_val], [q0, q1]) (linear) of a float32 tensor -> device float32 [2]."""
+    def percentiles(x, q0, q1, invalid_val=None, out=None, invalid_mask=None):
+        """Exact np.percentile(x[x != invalid_val], [q0, q1]) (linear) of a float32 tensor -> device float32 [2];
+        invalid_mask (uint8, same numel, non-zero = excluded) replaces the value test when given (color.py:121-122)."""
         assert x.dtype == torch.float32 and x.is_contiguous()
+        if invalid_mask is not None:
+            assert invalid_mask.dtype == torch.uint8 and invalid_mask.numel() == x.numel() and invalid_mask.is_contiguous()
         ws = torch.empty(_L.pf_percentile_workspace_bytes(), dtype=torch.uint8, device=x.device)
         out = torch.empty(2, dtype=torch.float32, device=x.device) if out is None else out
         check(_L.pf_percentiles_f32(_p(x), x.numel(), float(invalid_val if invalid_val is not None else 0.0), int(invalid_val is not None),
-                                    float(q0), float(q1), _p(out), _p(ws), _stream()), "pf_percentiles_f32")
+                                    _p(invalid_mask), float(q0), float(q1), _p(out), _p(ws), _stream()), "pf_percentiles_f32")
         return out
 
     @staticmethod
-    def colorize(depth, vmin_vmax, lut_rgba, N, invalid_val, background_rgba, out):
+    def colorize(depth, vmin_vmax, lut_rgba, N, invalid_val, background_rgba, out, invalid_mask=None):
         assert depth.dtype == torch.float32 and depth.is_contiguous() and vmin_vmax.dtype == torch.float32 and vmin_vmax.numel() == 2
         assert lut_rgba.dtype == torch.uint8 and lut_rgba.shape == (N + 3, 4) and lut_rgba.is_contiguous()
         assert out.dtype == torch.uint8 and out.numel() == depth.numel() * 4 and out.is_contiguous()
+        if invalid_mask is not None:
+            assert invalid_mask.dtype == torch.uint8 and invalid_mask.numel() == depth.numel() and invalid_mask.is_contiguous()
         r, g, b, a = (int(v) & 255 for v in background_rgba)
         check(_L.pf_colorize_f32(_p(depth), depth.numel(), _p(vmin_vmax), _p(lut_rgba), int(N), float(invalid_val if invalid_val is not None else 0.0),
-                                 int(invalid_val is not None), r | (g << 8) | (b << 16) | (a << 24), _p(out), _stream()), "pf_colorize_f32")
+                                 int(invalid_val is not None), _p(invalid_mask), r | (g << 8) | (b << 16) | (a << 24), _p(out), _stream()),
+              "pf_colorize_f32")
         return out
 
     @staticmethod
@@ -358,15 +382,18 @@ class HipOps:
         return loss
 
     @staticmethod
-    def depth_metrics(gt, pred, edges, min_depth, max_depth, crop, out13):
-        """gt [H,W], pred [h,w] float32, edges [H,W] float32 or None, crop = (y0, y1, x0, x1) -> out13 (device float64 [13])."""
+    def depth_metrics(gt, pred, edges, min_depth, max_depth, crop, out13, additional_mask=None):
+        """gt [H,W], pred [h,w] float32, edges [H,W] float32 or None, crop = (y0, y1, x0, x1), additional_mask [H,W] uint8 or None
+        (zero = excluded) -> out13 (device float64 [13])."""
         assert gt.dtype == torch.float32 and pred.dtype == torch.float32 and gt.dim() == 2 and pred.dim() == 2
         assert gt.is_contiguous() and pred.is_contiguous() and out13.dtype == torch.float64 and out13.numel() == 13
         if edges is not None:
             assert edges.dtype == torch.float32 and edges.shape == gt.shape and edges.is_contiguous()
+        if additional_mask is not None:
+            assert additional_mask.dtype == torch.uint8 and additional_mask.shape == gt.shape and additional_mask.is_contiguous()
         y0, y1, x0, x1 = (int(v) for v in crop)
-        check(_L.pf_depth_metrics(_p(gt), gt.shape[0], gt.shape[1], _p(pred), pred.shape[0], pred.shape[1], _p(edges), float(min_depth),
-                                  float(max_depth), y0, y1, x0, x1, _p(out13), _stream()), "pf_depth_metrics")
+        check(_L.pf_depth_metrics(_p(gt), gt.shape[0], gt.shape[1], _p(pred), pred.shape[0], pred.shape[1], _p(edges), _p(additional_mask),
+                                  float(min_depth), float(max_depth), y0, y1, x0, x1, _p(out13), _stream()), "pf_depth_metrics")
         return out13
 
 

@@ -139,9 +139,7 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
                 raise NotImplementedError
         if config.coarse_branch.type != config.fine_branch.type:
             raise NotImplementedError("coarse and fine branch of different types")
-        if config.coarse_branch.bin_centers_type != "softplus":
-            if config.coarse_branch.bin_centers_type in ("normed", "hybrid1", "hybrid2"):
-                raise NotImplementedError("only bin_centers_type='softplus' (the shipped configs) is built")
+        if config.coarse_branch.bin_centers_type not in ("normed", "softplus", "hybrid1", "hybrid2"):
             raise ValueError("bin_centers_type should be one of 'normed', 'softplus', 'hybrid1', 'hybrid2'")
         # patchfusion.py:82-87: ensure_multiple_of 32 for the MiDaS-core branch, 14 for Depth-Anything
         self.resizer = Resizer(self.patch_process_shape[1], self.patch_process_shape[0],

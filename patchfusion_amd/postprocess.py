@@ -16,6 +16,16 @@ def _ops():
     return ops
 
 
+def _plane_any(value):
+    """squeeze to one [H,W] plane, dtype kept (masks)"""
+    v = value.detach()
+    while v.dim() > 2 and v.shape[0] == 1:
+        v = v[0]
+    if v.dim() != 2:
+        raise ValueError(f"expected one map, got shape {tuple(value.shape)}")
+    return v
+
+
 def colormap_lut(cmap, device):
     """(N+3, 4) uint8 table of a matplotlib colormap (N colours + under / over / bad rows), scaled like
     Colormap.__call__(bytes=True); built once per (cmap, device) on the host - it is 1 KiB of constants."""
@@ -38,16 +48,28 @@ def _plane(value):
     return v.float().contiguous()
 
 
+def gamma_table():
+    """color.py:86-91 on one byte: (img / 255) ** 2.2 * 255 in float64, truncated by astype(uint8)."""
+    return (np.power(np.arange(256) / 255, 2.2) * 255).astype(np.uint8)
+
+
 def colorize(value, vmin=None, vmax=None, cmap="turbo_r", invalid_val=-99, invalid_mask=None, background_color=(128, 128, 128, 255),
              gamma_corrected=False, value_transform=None, vminp=2, vmaxp=95, ops=None):
     """estimator/utils/color.py:95-150 on the device: -> uint8 tensor [H,W,4] (RGBA).  vmin / vmax default to the
-    exact 2nd / 95th percentile of the valid pixels (radix select, no sort, no host round trip)."""
-    if invalid_mask is not None or gamma_corrected or value_transform is not None:
-        raise NotImplementedError("colorize: invalid_mask / gamma_corrected / value_transform are not used on the inference path")
+    exact 2nd / 95th percentile of the valid pixels (radix select, no sort, no host round trip).
+
+    invalid_mask (bool, same grid; numpy or tensor) replaces the `value == invalid_val` test as in the reference (:121-122).
+    gamma_corrected is a per-byte function (:86-91), so it is applied to the 1 KiB colour table and the background colour, not to the
+    image.  value_transform is an arbitrary python callable on the normalised numpy array (:140-141): only in that case the
+    normalised plane makes one host round trip (the reference hands the callable a numpy array with NaN at the invalid pixels)."""
     ops = ops or _ops()
     d = _plane(value)
+    m = None
+    if invalid_mask is not None:
+        m = torch.as_tensor(np.asarray(invalid_mask.detach().cpu()) if isinstance(invalid_mask, torch.Tensor) else np.asarray(invalid_mask))
+        m = (m.reshape(d.shape) != 0).to(torch.uint8).to(d.device).contiguous()
     if vmin is None or vmax is None:
-        vmm = ops.percentiles(d, vminp, vmaxp, invalid_val=invalid_val)
+        vmm = ops.percentiles(d, vminp, vmaxp, invalid_val=invalid_val, invalid_mask=m)
         if vmin is not None:
             vmm[0] = float(vmin)
         if vmax is not None:
@@ -55,8 +77,23 @@ def colorize(value, vmin=None, vmax=None, cmap="turbo_r", invalid_val=-99, inval
     else:
         vmm = torch.tensor([float(vmin), float(vmax)], dtype=torch.float32).to(d.device)
     lut, N = colormap_lut(cmap, d.device)
+    bg = tuple(int(v) & 255 for v in background_color)
+    if gamma_corrected:
+        g = gamma_table()
+        lut = torch.from_numpy(g[lut.cpu().numpy()]).to(d.device).contiguous()
+        bg = tuple(int(g[v]) for v in bg)
     out = torch.empty(d.shape + (4,), dtype=torch.uint8, device=d.device)
-    return ops.colorize(d, vmm, lut, N, invalid_val, background_color, out)
+    if value_transform is not None:
+        if m is None:
+            m = (d == invalid_val).to(torch.uint8) if invalid_val is not None else torch.zeros_like(d, dtype=torch.uint8)
+        lo, hi = (np.float32(t) for t in vmm.tolist())
+        x = d.cpu().numpy()
+        x = (x - lo) / (hi - lo) if lo != hi else x * np.float32(0)
+        x[m.cpu().numpy() != 0] = np.nan
+        x = np.ascontiguousarray(np.asarray(value_transform(x), dtype=np.float32))
+        d = torch.from_numpy(x).to(d.device)
+        vmm = torch.tensor([0.0, 1.0], dtype=torch.float32).to(d.device)        # (x - 0) / (1 - 0) == x exactly
+    return ops.colorize(d, vmm, lut, N, invalid_val, bg, out, invalid_mask=m)
 
 
 def depth_to_uint16(depth, ops=None):
@@ -94,8 +131,6 @@ def compute_metrics(gt, pred, interpolate=True, garg_crop=False, eigen_crop=True
                     disp_gt_edges=None, additional_mask=None, ops=None):
     """estimator/utils/metric.py:87-148 on the device (signature and defaults of the reference).  pred is resized to
     the ground-truth grid inside the kernel when `interpolate` and the grids differ."""
-    if additional_mask is not None:
-        raise NotImplementedError("compute_metrics: additional_mask (prompt-depth evaluation) is outside the tiled-inference path")
     ops = ops or _ops()
     g, p = _plane(gt), _plane(pred)
     if g.shape != p.shape and not interpolate:
@@ -103,8 +138,12 @@ def compute_metrics(gt, pred, interpolate=True, garg_crop=False, eigen_crop=True
     e = None
     if disp_gt_edges is not None:
         e = _plane(disp_gt_edges.to(g.device))
+    am = None
+    if additional_mask is not None:                                           # metric.py:128-130 (prompt-depth evaluation)
+        am = (_plane_any(additional_mask.to(g.device)) != 0).to(torch.uint8).contiguous()
     out = torch.empty(13, dtype=torch.float64, device=g.device)
-    ops.depth_metrics(g, p, e, min_depth_eval, max_depth_eval, crop_rectangle(g.shape[0], g.shape[1], garg_crop, eigen_crop, dataset), out)
+    ops.depth_metrics(g, p, e, min_depth_eval, max_depth_eval, crop_rectangle(g.shape[0], g.shape[1], garg_crop, eigen_crop, dataset), out,
+                      additional_mask=am)
     s = out.cpu().tolist()
     r = metrics_from_sums(s)
     if disp_gt_edges is not None:

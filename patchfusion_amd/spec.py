@@ -115,9 +115,10 @@ def dpt_head_spec(d, p, enc):
     _conv(d, p + "scratch.output_conv2.2", 1, N_MIDAS_OUT, 1)
 
 
-def bins_head_spec(d, p, C, n_bins, emb, n_attractors):
+def bins_head_spec(d, p, C, n_bins, emb, n_attractors, bin_centers_type="softplus"):
     """The metric-bins head; shared by ZoeDepth (zoedepth_v1.py:84-123) and the fusion head
-    (patchfusion.py:149-170)."""
+    (patchfusion.py:149-170).  The bounded attractor layer ('normed' / 'hybrid2', attractor.py:81) has 2 x n_attractors outputs."""
+    amul = 2 if bin_centers_type in ("normed", "hybrid2") else 1
     _conv(d, p + "seed_bin_regressor._net.0", 256, C, 1)
     _conv(d, p + "seed_bin_regressor._net.2", n_bins, 256, 1)
     _conv(d, p + "seed_projector._net.0", 128, C, 1)
@@ -127,7 +128,7 @@ def bins_head_spec(d, p, C, n_bins, emb, n_attractors):
         _conv(d, f"{p}projectors.{i}._net.2", emb, 128, 1)
     for i in range(4):
         _conv(d, f"{p}attractors.{i}._net.0", 128, emb, 1)
-        _conv(d, f"{p}attractors.{i}._net.2", n_attractors[i], 128, 1)
+        _conv(d, f"{p}attractors.{i}._net.2", n_attractors[i] * amul, 128, 1)
     d[p + "conditional_log_binomial.log_binomial_transform.k_idx"] = Entry((1, n_bins, 1, 1), torch.int64, "k_idx")
     d[p + "conditional_log_binomial.log_binomial_transform.K_minus_1"] = Entry((1, 1, 1, 1), torch.float32, "k_minus_1")
     cin = N_MIDAS_OUT + 1 + emb
@@ -159,7 +160,7 @@ def branch_spec(d, p, bcfg):
         vit_spec(d, p + "core.core.pretrained.", enc)
         dpt_head_spec(d, p + "core.core.depth_head.", enc)
     _conv(d, p + "conv2", C, C, 1)
-    bins_head_spec(d, p, C, bcfg["n_bins"], bcfg["bin_embedding_dim"], bcfg["n_attractors"])
+    bins_head_spec(d, p, C, bcfg["n_bins"], bcfg["bin_embedding_dim"], bcfg["n_attractors"], bcfg.get("bin_centers_type", "softplus"))
 
 
 GF_DEFAULT_IN_CHANNELS = [32, 256, 256, 256, 256, 256]                      # guided_fusion_model.py:108
@@ -226,7 +227,7 @@ def patchfusion_spec(cfg):
         else:
             _conv(d, f"fusion_conv_list.{i}", C, 2 * C, 3)
     guided_fusion_spec(d, "guided_fusion.", cfg["guided_fusion"])
-    bins_head_spec(d, "", C, cb["n_bins"], cb["bin_embedding_dim"], cb["n_attractors"])
+    bins_head_spec(d, "", C, cb["n_bins"], cb["bin_embedding_dim"], cb["n_attractors"], cb.get("bin_centers_type", "softplus"))
     return d
 
 

@@ -225,12 +225,32 @@ class FakeOps:
         return x[..., :Cc].float().permute(0, 3, 1, 2).contiguous()
 
     @staticmethod
-    def attractor(A, n_attr, b_prev, out):
+    def attractor(A, n_attr, b_prev, out, a_stride=1, a_eps=0.0, attractor_type="inv", kind="mean"):
         h, w = out.shape[1:3]
         c = F.interpolate(b_prev.permute(0, 3, 1, 2), size=(h, w), mode="bilinear", align_corners=True)   # [B,nb,h,w]
-        a = A[..., :n_attr].permute(0, 3, 1, 2)
+        a = A[..., :n_attr * a_stride:a_stride].permute(0, 3, 1, 2) + a_eps
         dx = a.unsqueeze(2) - c.unsqueeze(1)
-        out[:] = (c + (dx / (1 + 300.0 * dx.pow(2))).mean(dim=1)).permute(0, 2, 3, 1)
+        d = torch.exp(-300.0 * dx.abs() ** 2) * dx if attractor_type == "exp" else dx / (1 + 300.0 * dx.pow(2))
+        out[:] = (c + (d.mean(dim=1) if kind == "mean" else d.sum(dim=1))).permute(0, 2, 3, 1)
+
+    @staticmethod
+    def seed_bin_centers(x, out, min_depth, max_depth, bounded, normalize):
+        nb = out.shape[-1]
+        c = x[..., :nb].float()
+        if bounded:
+            Bn = c + 1e-3
+            widths = (max_depth - min_depth) * (Bn / Bn.sum(dim=-1, keepdim=True))
+            edges = torch.cumsum(torch.cat([torch.full_like(widths[..., :1], min_depth), widths], dim=-1), dim=-1)
+            c = 0.5 * (edges[..., :-1] + edges[..., 1:])
+        if normalize:
+            c = (c - min_depth) / (max_depth - min_depth)
+        out[:] = c
+        return out
+
+    @staticmethod
+    def bounded_bin_centers(b, out, min_depth, max_depth):
+        out[:] = torch.clip(torch.sort((max_depth - min_depth) * b + min_depth, dim=-1)[0], min_depth, max_depth)
+        return out
 
     @staticmethod
     def logbinom_depth(pt, centers, depth, min_temp, max_temp):
@@ -294,10 +314,12 @@ class FakeOps:
         return out
 
     @staticmethod
-    def percentiles(x, q0, q1, invalid_val=None, out=None):
+    def percentiles(x, q0, q1, invalid_val=None, out=None, invalid_mask=None):
         from oracle import io_oracle
         v = x.cpu().numpy().ravel()
-        if invalid_val is not None:
+        if invalid_mask is not None:
+            v = v[invalid_mask.cpu().numpy().ravel() == 0]
+        elif invalid_val is not None:
             v = v[v != invalid_val]
         r = torch.tensor([float(io_oracle.percentile_linear(v, q0)), float(io_oracle.percentile_linear(v, q1))], dtype=torch.float32)
         if out is not None:
@@ -306,11 +328,14 @@ class FakeOps:
         return r.to(x.device)
 
     @staticmethod
-    def colorize(depth, vmin_vmax, lut_rgba, N, invalid_val, background_rgba, out):
+    def colorize(depth, vmin_vmax, lut_rgba, N, invalid_val, background_rgba, out, invalid_mask=None):
         import numpy as np
         from oracle import io_oracle
         v = depth.cpu().numpy().copy()
-        inv = (v == invalid_val) if invalid_val is not None else np.zeros(v.shape, bool)
+        if invalid_mask is not None:
+            inv = invalid_mask.cpu().numpy().reshape(v.shape) != 0
+        else:
+            inv = (v == invalid_val) if invalid_val is not None else np.zeros(v.shape, bool)
         vmin, vmax = (np.float32(t) for t in vmin_vmax.tolist())
         v = (v - vmin) / (vmax - vmin) if vmin != vmax else v * np.float32(0)
         v[inv] = np.nan
@@ -333,7 +358,7 @@ class FakeOps:
         return 10 * torch.sqrt(torch.var(g) + beta * torch.pow(torch.mean(g), 2))
 
     @staticmethod
-    def depth_metrics(gt, pred, edges, min_depth, max_depth, crop, out13):
+    def depth_metrics(gt, pred, edges, min_depth, max_depth, crop, out13, additional_mask=None):
         import numpy as np
         from oracle import io_oracle
         if gt.shape != pred.shape:
@@ -348,6 +373,8 @@ class FakeOps:
         em = np.zeros(m.shape, bool)
         em[crop[0]:crop[1], crop[2]:crop[3]] = True
         m &= em
+        if additional_mask is not None:
+            m &= additional_mask.cpu().numpy() != 0
         gv, pv = g[m].astype(np.float32), p[m].astype(np.float32)
         th = np.maximum(gv / pv, pv / gv)
         lg, lp = np.log(gv), np.log(pv)

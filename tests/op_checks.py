@@ -402,6 +402,26 @@ def bins_ops(dt):
             o.attractor(A, n_attr, bp, out)
             res.append(out)
         errs.append(_err(res[0], res[1]))
+    # the bounded layers and the other attractor type / kind (bin_centers_type 'normed' / 'hybrid*', attractor.py:60-136)
+    A2 = torch.relu(_rand((2, 16, 22, 32), torch.float32, 21))
+    bp = torch.rand((2, 8, 11, 64), generator=torch.Generator().manual_seed(22)).to(DEV)
+    for kw in (dict(a_stride=2, a_eps=1e-3), dict(a_stride=2, a_eps=1e-3, attractor_type="exp", kind="sum"), dict(attractor_type="exp"), dict(kind="sum")):
+        res = []
+        for o in (hip(), ref_ops):
+            out = torch.zeros((2, 16, 22, 64), device=DEV)
+            o.attractor(A2, 16, bp, out, **kw)
+            res.append(out)
+        errs.append(_err(res[0], res[1]))
+    x = torch.relu(_rand((2, 9, 13, 64), torch.float32, 23))
+    for bounded, normalize in ((True, True), (True, False), (False, True)):
+        res = [o.seed_bin_centers(x, torch.zeros((2, 9, 13, 64), device=DEV), 1e-3, 80.0, bounded, normalize) for o in (hip(), ref_ops)]
+        errs.append(_err(res[0], res[1]) / (1.0 if normalize else 80.0))
+    for nb in (64, 16):
+        b = _rand((3, 17, 19, nb), torch.float32, 24) * 0.6 + 0.5          # some outside [0, 1] -> clipped, unsorted, with ties
+        b[0, :4] = b[0, :4].round()
+        res = [o.bounded_bin_centers(b, torch.zeros_like(b), 1e-3, 80.0) for o in (hip(), ref_ops)]
+        errs.append(float((res[0] - res[1]).abs().max()) / 80.0)
+        assert bool((res[0][..., 1:] >= res[0][..., :-1]).all())
     pt = torch.nn.functional.softplus(_rand((2, 56, 77, 4), torch.float32, 5) + torch.tensor([0, 0, -4.0, 1.0], device=DEV))
     cen = torch.nn.functional.softplus(_rand((2, 32, 44, 64), torch.float32, 6))
     res = []

@@ -226,3 +226,20 @@ def test_train_mode_forward_vs_oracle():
     # degenerate mask: <= 1 valid pixel -> 0 (losses.py:38-40)
     z = m.ops.silog_loss(aux["depth_pred"].contiguous(), torch.zeros_like(aux["depth_pred"]), 1e-3, 80)
     assert float(z) == 0.0
+
+
+@pytest.mark.parametrize("kind,atype,akind", [("normed", "inv", "mean"), ("hybrid1", "exp", "sum"), ("hybrid2", "inv", "sum"), ("softplus", "exp", "mean")])
+def test_bin_center_variants_fp32_match_reference_golden(golden_dir, kind, atype, akind):
+    """bin_centers_type 'normed' / 'hybrid1' / 'hybrid2' (bounded seed regressor / attractor layer, zoedepth_v1.py:90-104) and
+    attractor_type 'exp' / attractor_kind 'sum': whole path on the HIP engine against the reference-made fixture
+    (tests/golden/variants_vits.npz).  Depth ranges differ per variant (up to 62), so the 2e-4 bar is relative to max |depth|."""
+    from oracle.make_golden import variant_case
+    g = np.load(os.path.join(golden_dir, "variants_vits.npz"))
+    cfg, sd, img = variant_case(kind, atype, akind)
+    m = PatchFusion(cfg, compute_dtype="fp32").eval()
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    d, _ = m(mode="infer", image_lr=m.resizer(img).cuda(), image_hr=img.cuda(), cai_mode="m1", process_num=2)
+    ref = g[f"{kind}_depth_m1"]
+    err = np.abs(d[0, 0].cpu().numpy() - ref).max()
+    assert err <= 2e-4 * max(1.0, np.abs(ref).max()), (kind, err)

@@ -119,3 +119,26 @@ def test_product_path_has_no_cpu_fallback():
     m = PatchFusion(cfg)   # default ops = hip_ops
     with pytest.raises(Exception):
         m(mode="infer", image_lr=torch.zeros(1, 3, 112, 154), image_hr=torch.zeros(1, 3, 448, 616))
+
+
+@pytest.mark.parametrize("kind,atype,akind", [("normed", "inv", "mean"), ("hybrid1", "exp", "sum"), ("hybrid2", "inv", "sum"), ("softplus", "exp", "mean")])
+def test_bin_center_variants_match_reference_golden(golden_dir, kind, atype, akind):
+    """bin_centers_type / attractor_type / attractor_kind wiring (engine.BinsHead) against the reference-made fixture"""
+    from oracle.make_golden import variant_case
+    g = np.load(os.path.join(golden_dir, "variants_vits.npz"))
+    cfg, sd, img = variant_case(kind, atype, akind)
+    m = PatchFusion(cfg, compute_dtype="fp32", ops=fake_ops).eval()
+    m.load_state_dict(sd, strict=True)
+    d, _ = m(mode="infer", image_lr=m.resizer(img), image_hr=img, cai_mode="m1", process_num=2)
+    ref = g[f"{kind}_depth_m1"]
+    assert tuple(d.shape[2:]) == ref.shape
+    assert np.abs(d[0, 0].numpy() - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), kind
+    ref = g[f"{kind}_coarse_depth"]
+    assert np.abs(m._coarse_state["depth"][0].numpy() - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_bin_centers_type_error_contract():
+    cfg = make_config(*TINY)
+    cfg["coarse_branch"]["bin_centers_type"] = "bogus"
+    with pytest.raises(ValueError, match="bin_centers_type should be one of"):
+        PatchFusion(cfg, compute_dtype="fp32", ops=fake_ops)

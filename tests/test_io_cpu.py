@@ -42,6 +42,23 @@ def test_colorize_and_uint16_host_logic():
     assert u.dtype == torch.uint16 and np.array_equal(u.numpy(), G["uint16"])
 
 
+def test_colorize_optional_arguments_host_logic():
+    d, im = torch.from_numpy(G["depth"])[None, None], G["invalid_mask"]
+    lo, hi = (float(np.float32(v)) for v in G["np_percentiles"])
+    lom, him = (float(np.float32(v)) for v in G["np_percentiles_mask"])
+    kw = dict(ops=fake)
+    assert np.array_equal(post.colorize(d, vmin=lom, vmax=him, cmap="magma_r", invalid_mask=im, **kw).numpy(), G["colorize_mask"])
+    assert np.array_equal(post.colorize(d, vmin=lom, vmax=him, cmap="magma_r", invalid_mask=torch.from_numpy(im)[None], **kw).numpy(),
+                          G["colorize_mask"])
+    assert np.array_equal(post.colorize(d, vmin=lo, vmax=hi, cmap="magma_r", gamma_corrected=True, **kw).numpy(), G["colorize_gamma"])
+    assert np.array_equal(post.colorize(d, vmin=lo, vmax=hi, cmap="gray_r", value_transform=np.square, **kw).numpy(), G["colorize_transform"])
+    assert np.array_equal(post.colorize(d, vmin=lom, vmax=him, cmap="turbo_r", invalid_mask=im, gamma_corrected=True, value_transform=np.square,
+                                        background_color=(10, 200, 30, 255), **kw).numpy(), G["colorize_all"])
+    # percentiles taken over the masked selection
+    img = post.colorize(d, cmap="magma_r", invalid_mask=im, **kw).numpy()
+    assert (np.abs(img.astype(int) - G["colorize_mask"].astype(int)).max(-1) > 0).mean() < 2e-3
+
+
 def test_compute_metrics_host_logic():
     gt, pred, edges = (torch.from_numpy(G[k]) for k in ("gt", "pred", "edges"))
     r = post.compute_metrics(gt[None, None], pred[None, None], min_depth_eval=1e-3, max_depth_eval=80, garg_crop=False, eigen_crop=False,
@@ -53,5 +70,8 @@ def test_compute_metrics_host_logic():
                              garg_crop=True, eigen_crop=False, dataset="u4k", ops=fake)
     keys = [str(k) for k in G["metrics_resize_garg_keys"]]
     np.testing.assert_allclose([r[k] for k in keys], G["metrics_resize_garg"], rtol=2e-5)
+    r = post.compute_metrics(gt[None, None], pred[None, None], min_depth_eval=1e-3, max_depth_eval=80, garg_crop=False, eigen_crop=False,
+                             disp_gt_edges=edges[None], additional_mask=torch.from_numpy(G["additional_mask"])[None, None], ops=fake)
+    np.testing.assert_allclose([r[k] for k in [str(k) for k in G["metrics_same_keys"]]], G["metrics_addmask"], rtol=2e-5)
     assert post.crop_rectangle(480, 640, False, True, "nyu") == (45, 471, 41, 601)
     assert post.crop_rectangle(100, 200, False, False, "nyu") == (0, 100, 0, 200)

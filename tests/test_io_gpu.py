@@ -98,6 +98,32 @@ def test_colorize_and_uint16_bit_exact():
     assert np.array_equal(post.depth_to_uint16(torch.from_numpy(np.abs(big)).cuda()).cpu().numpy(), io.depth_to_uint16(np.abs(big)))
 
 
+def test_colorize_optional_arguments_bit_exact():
+    """invalid_mask / gamma_corrected / value_transform (color.py:121-122, :86-91, :140-141) vs the reference-made fixtures and, at the
+    stitched-map size with own percentiles, vs the oracle"""
+    io, post, ops, _ = _mods()
+    d, im = torch.from_numpy(G["depth"]).cuda()[None, None], G["invalid_mask"]
+    lo, hi = (float(np.float32(v)) for v in G["np_percentiles"])
+    lom, him = (float(np.float32(v)) for v in G["np_percentiles_mask"])
+    assert np.array_equal(post.colorize(d, vmin=lom, vmax=him, cmap="magma_r", invalid_mask=im).cpu().numpy(), G["colorize_mask"])
+    assert np.array_equal(post.colorize(d, vmin=lo, vmax=hi, cmap="magma_r", gamma_corrected=True).cpu().numpy(), G["colorize_gamma"])
+    assert np.array_equal(post.colorize(d, vmin=lo, vmax=hi, cmap="gray_r", value_transform=np.square).cpu().numpy(), G["colorize_transform"])
+    assert np.array_equal(post.colorize(d, vmin=lom, vmax=him, cmap="turbo_r", invalid_mask=torch.from_numpy(im).cuda(), gamma_corrected=True,
+                                        value_transform=np.square, background_color=(10, 200, 30, 255)).cpu().numpy(), G["colorize_all"])
+    rs = np.random.RandomState(4)
+    big = (rs.rand(1568, 2072) ** 2 * 40).astype(np.float32)
+    big[rs.rand(1568, 2072) < 0.02] = -99
+    bm = rs.rand(1568, 2072) < 0.3
+    for kw in (dict(invalid_mask=bm), dict(invalid_mask=bm, gamma_corrected=True, value_transform=np.sqrt), dict(gamma_corrected=True)):
+        with np.errstate(invalid="ignore"):
+            ref = io.colorize(big, cmap="magma_r", **kw)
+            got = post.colorize(torch.from_numpy(big).cuda(), cmap="magma_r", **kw).cpu().numpy()
+        assert np.array_equal(got, ref), sorted(kw)
+    # masked percentiles alone (radix select over the mask's complement)
+    p = ops.percentiles(torch.from_numpy(big).cuda(), 2, 95, invalid_val=-99, invalid_mask=torch.from_numpy(bm.astype(np.uint8)).cuda()).cpu().numpy()
+    assert p[0] == io.percentile_linear(big[~bm], 2) and p[1] == io.percentile_linear(big[~bm], 95)
+
+
 def test_metrics_vs_reference_fixture_and_oracle():
     io, post, ops, _ = _mods()
     gt, pred, edges = (torch.from_numpy(G[k]) for k in ("gt", "pred", "edges"))
@@ -110,6 +136,9 @@ def test_metrics_vs_reference_fixture_and_oracle():
                              max_depth_eval=80, garg_crop=True, eigen_crop=False, dataset="u4k")
     keys = [str(k) for k in G["metrics_resize_garg_keys"]]
     np.testing.assert_allclose([r[k] for k in keys], G["metrics_resize_garg"], rtol=2e-5)
+    r = post.compute_metrics(gt.cuda()[None, None], pred.cuda()[None, None], min_depth_eval=1e-3, max_depth_eval=80, garg_crop=False,
+                             eigen_crop=False, disp_gt_edges=edges[None], additional_mask=torch.from_numpy(G["additional_mask"])[None, None])
+    np.testing.assert_allclose([r[k] for k in [str(k) for k in G["metrics_same_keys"]]], G["metrics_addmask"], rtol=2e-5)
     # BASELINE geometry: 4K ground truth, stitched 1568x2072 prediction (resize inside the kernel), boundaries
     rs = np.random.RandomState(9)
     yy, xx = np.mgrid[0:540, 0:960].astype(np.float32)

@@ -66,6 +66,26 @@ def test_colorize_matches_reference():
     assert (G["colorize_magma_r"][d == -99] == np.array([128, 128, 128, 255])).all()
 
 
+def test_colorize_optional_arguments_match_reference():
+    """color.py:121-122 invalid_mask, :140-141 value_transform, :86-91 gamma_corrected -- fixtures made by the reference's colorize"""
+    d, im = G["depth"], G["invalid_mask"]
+    lo, hi = (np.float32(v) for v in G["np_percentiles"])
+    lom, him = (np.float32(v) for v in G["np_percentiles_mask"])
+    assert np.array_equal(io.colorize(d, vmin=lom, vmax=him, cmap="magma_r", invalid_mask=im), G["colorize_mask"])
+    assert np.array_equal(io.colorize(d, vmin=lo, vmax=hi, cmap="magma_r", gamma_corrected=True), G["colorize_gamma"])
+    assert np.array_equal(io.colorize(d, vmin=lo, vmax=hi, cmap="gray_r", value_transform=np.square), G["colorize_transform"])
+    assert np.array_equal(io.colorize(d, vmin=lom, vmax=him, cmap="turbo_r", invalid_mask=im, gamma_corrected=True, value_transform=np.square,
+                                      background_color=(10, 200, 30, 255)), G["colorize_all"])
+    # with an explicit mask the -99 pixels outside it are ordinary values (far below vmin -> the colormap's "under" colour)
+    out = (d == -99) & ~im
+    assert out.any() and (G["colorize_mask"][out] != np.array([128, 128, 128, 255])).any(axis=-1).all()
+    # gamma touches the background and the alpha channel too: 128 -> int((128/255)**2.2*255) = 55, 255 -> 255
+    assert (G["colorize_gamma"][d == -99] == np.array([55, 55, 55, 255])).all()
+    # own percentiles (numpy 1.24 semantics) with the mask
+    diff = np.abs(io.colorize(d, cmap="magma_r", invalid_mask=im).astype(int) - G["colorize_mask"].astype(int)).max(axis=-1)
+    assert (diff > 0).mean() < 2e-3
+
+
 def test_uint16_matches_reference():
     assert np.array_equal(io.depth_to_uint16(np.abs(G["depth"])), G["uint16"])
 
@@ -81,3 +101,8 @@ def test_compute_metrics_matches_reference():
     keys = [str(k) for k in G["metrics_resize_garg_keys"]]
     np.testing.assert_allclose([float(r[k]) for k in keys], G["metrics_resize_garg"], rtol=1e-6)
     assert "see" not in r
+    r = io.compute_metrics(gt[None, None], pred[None, None], min_depth_eval=1e-3, max_depth_eval=80, disp_gt_edges=edges[None],
+                           additional_mask=torch.from_numpy(G["additional_mask"])[None, None])
+    keys = [str(k) for k in G["metrics_same_keys"]]
+    np.testing.assert_allclose([float(r[k]) for k in keys], G["metrics_addmask"], rtol=1e-6)
+    assert abs(G["metrics_addmask"] - G["metrics_same"]).max() > 0

@@ -73,7 +73,7 @@ def main():
         return
     if args.roofline_only:
         torch.cuda.set_device(0)
-        print(json.dumps(roofline(args.dtype, torch.device("cuda", 0))), flush=True)
+        print(json.dumps(roofline(args.dtype, torch.device("cuda", 0), gemm_only=True)), flush=True)   # one kernel only: PMC passes
         return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -218,9 +218,16 @@ def kernel_source_sha():
     return h.hexdigest()[:12]
 
 
-def roofline(dtype, dev):
-    """Dominant kernel: the fusion U-Net's 3x3 conv 544->544 @ [8,392,518] (vitl), through the same pf_conv entry point
-    the engine uses: algorithmic FLOPs = 2 * 8*392*518 * 9*544 * 544 per launch.
+def roofline(dtype, dev, gemm_only=False):
+    """Dominant kernel of the pass, timed live through the entry points the engine uses (HIP events on the launch stream).
+
+    bf16: the 3x3 halo kernel on the fusion U-Net's 544->544 conv @ [8,392,518]; algorithmic FLOPs = 2 * 8*392*518 * 9*544 * 544 per
+    launch.
+    fp32: the large 3x3 layers run as Winograd F(m x m, 3x3) (csrc/winograd.hip); the dominant launch is the f32 implicit-GEMM kernel
+    on the (m+2)^2 transform-point planes of that same layer, one batched launch: FLOPs = (m+2)^2 * 2 * T * 544 * 544 with
+    T = 8 * ceil(392/m) * ceil(518/m) tiles -- the GEMM's OWN multiply-adds, priced against the f32 MFMA peak.  `layer` adds the
+    whole three-step layer: its time and the direct-convolution FLOPs it replaces per second (which may exceed the MFMA peak:
+    Winograd multiplies (m+2)^2 / (9 m^2) as often).  PF_WINOGRAD=0: the direct f32 kernel on the 3x3 layer, as in bf16.
     `traffic` (HBM bytes per launch from the rocprofv3 PMC passes, which cannot run inside bench.py) is reported only when
     profiles/r2_pmc_dominant_<dtype>.json was measured on EXACTLY this kernel source (sha of igemm.hip); otherwise null."""
     from patchfusion_amd import packing as pk
@@ -229,24 +236,47 @@ def roofline(dtype, dev):
     B, H, W, C = 8, 392, 518, 544
     w = torch.randn(C, C, 3, 3) / (9 * C) ** 0.5
     pw = pk.pack_conv(w, torch.zeros(C), dtype=tdt).to(dev)
-    x = torch.randn(B, H, W, C, device=dev).to(tdt)
-    y = torch.empty(B, H, W, C, device=dev, dtype=tdt)
-    ms = ops.conv(x, pw, y, pad=1, act="relu", _timed=5)
-    flops = 2.0 * B * H * W * 9 * C * C
-    ach = flops / (ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[dtype]
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", f"r2_pmc_dominant_{dtype}.json")) as f:
             j = json.load(f)
-        if j.get("kernel_source_sha") == kernel_source_sha():
+        if j.get("kernel_source_sha") == kernel_source_sha() and j.get("winograd_m", 0) == pw.wino_m:
             traffic = j["derived"]["traffic_bytes"]
     except Exception:
         pass
+    direct_flops = 2.0 * B * H * W * 9 * C * C
+    if pw.wino_u is not None and pk.winograd_applies(pw, B * H * W, 1, 1, "relu"):
+        m = pw.wino_m
+        a2 = (m + 2) ** 2
+        T = B * -(-H // m) * -(-W // m)
+        V = torch.randn(a2 * T * C, device=dev)
+        Mw = torch.empty(a2 * T * C, device=dev)
+        ms = ops.gemm_planes_timed(V, pw.wino_u, Mw, a2, T, C, C, 5)
+        flops = a2 * 2.0 * T * C * C
+        ach = flops / (ms * 1e-3) / 1e12
+        out = {"bound": "mfma",
+               "kernel": f"conv_igemm_kernel<float> (v_mfma_f32_16x16x4_f32) as the batched Winograd-domain GEMM of the largest layer: "
+                         f"{a2} planes x [{T} x {C}].[{C} x {C}] = 3x3 {C}->{C} @ {B}x{H}x{W} (GuidedFusion up-conv) under F({m}x{m},3x3)",
+               "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+               "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "traffic": traffic, "winograd_m": m}
+        del V, Mw
+        if not gemm_only:
+            x = torch.randn(B, H, W, C, device=dev)
+            y = torch.empty(B, H, W, C, device=dev)
+            ms_layer = ops.conv(x, pw, y, pad=1, act="relu", _timed=5)
+            out["layer"] = {"what": f"whole layer = input transform + batched GEMM + output transform/epilogue, 3x3 {C}->{C} @ {B}x{H}x{W}",
+                            "ms": round(ms_layer, 4), "transforms_ms": round(ms_layer - ms, 4), "direct_conv_flops": direct_flops,
+                            "direct_conv_tflops_equivalent": round(direct_flops / (ms_layer * 1e-3) / 1e12, 2)}
+        return out
+    x = torch.randn(B, H, W, C, device=dev).to(tdt)
+    y = torch.empty(B, H, W, C, device=dev, dtype=tdt)
+    ms = ops.conv(x, pw, y, pad=1, act="relu", _timed=5)
+    ach = direct_flops / (ms * 1e-3) / 1e12
     kern = {"bf16": "conv3x3_halo_kernel (bf16, v_mfma_f32_32x32x16_bf16)", "fp32": "conv3x3 f32 kernel (v_mfma_f32_16x16x4_f32)"}[dtype]
     return {"bound": "mfma", "kernel": f"{kern}: 3x3 544->544 @ 8x392x518, the GuidedFusion up-conv = largest op",
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-            "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "traffic": traffic}
+            "ms_per_launch": round(ms, 4), "flops_per_launch": direct_flops, "traffic": traffic}
 
 
 def cpu_baseline(cfg, sd, img):

@@ -56,11 +56,23 @@ typedef struct {
   int shuffle;   /* s>1: ConvTranspose2d(kernel=stride=s): N = s*s*Cout_t, y is [B,OH*s,OW*s,Cout_t] */
   int dtype;
   int korder;    /* K order of w: 0 = (ky,kx,c); 1 = (c/32, ky, kx, c%32), f32 only, Cin % 32 == 0 (see packing.py) */
+  int batch;     /* > 1: that many independent GEMM planes in ONE launch (float32, no bias / scale / residual): plane k reads
+                    x + k*x_bstride, w + k*w_bstride and writes y + k*y_bstride (strides in elements); 0 / 1 = a single plane.
+                    Used for the (m+2)^2 transform points of a Winograd layer (pf_conv_winograd). */
+  long x_bstride, w_bstride, y_bstride;
 } pf_conv_params;
 int pf_conv(const pf_conv_params* p, void* stream);
 /* timing helper for the roofline entry of bench.py: runs `iters` launches bracketed by HIP events on
  * `stream`, returns the average milliseconds per launch in *ms */
 int pf_conv_timed(const pf_conv_params* p, int iters, float* ms, void* stream);
+
+/* Winograd F(m x m, 3 x 3), m = 2 or 4, for float32 3x3 / stride 1 / pad 1 layers (same reference layers as pf_conv): `p` describes
+ * the convolution exactly as for pf_conv (x, bias, res, res2, y, act NONE | RELU, relu_in; p->w is not read; scale must be NULL,
+ * Cin % 32 == 0, Cout % 8 == 0); U = the (m+2)^2 transformed filters G g G^T, each packed like a 1x1 pf_conv weight [u_rows][u_kpad]
+ * (patchfusion_amd/packing.py winograd_filters); V, M = device workspaces of (m+2)^2 * T * Cin and (m+2)^2 * T * Cout floats,
+ * T = B * ceil(H/m) * ceil(W/m).  Input transform -> (m+2)^2 GEMMs through pf_conv -> output transform + epilogue (winograd.hip).
+ * m = 2 multiplies 2.25x less than the direct convolution at ~2.5x its float32 rounding error, m = 4 4x less at ~15x. */
+int pf_conv_winograd(const pf_conv_params* p, int m, const void* U, int u_rows, int u_kpad, void* V, void* M, void* stream);
 
 /* ---- ViT encoder pieces ---------------------------------------------------------------------- */
 /* (x - mean)/std + 14x14/14 patch gather: NCHW float image -> im2col rows [B*th*tw][ld] (K order

@@ -22,6 +22,7 @@ class ConvParams(C.Structure):
         ("y", vp), ("y_ld", ci), ("OH", ci), ("OW", ci), ("Cout", ci),
         ("KH", ci), ("KW", ci), ("stride", ci), ("pad", ci),
         ("act", ci), ("relu_in", ci), ("out_f32", ci), ("shuffle", ci), ("dtype", ci), ("korder", ci),
+        ("batch", ci), ("x_bstride", C.c_long), ("w_bstride", C.c_long), ("y_bstride", C.c_long),
     ]
 
 
@@ -46,6 +47,7 @@ SIGNATURES = {
     "pf_copy_channels": [vp, ci, vp, ci, cl, ci, ci, ci, ci, vp],
     "pf_pack_fusion_input": [vp, vp, vp, vp, ci, ci, ci, ci, vp],
     "pf_nhwc_to_nchw_f32": [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp],
+    "pf_conv_winograd": [C.POINTER(ConvParams), ci, vp, ci, ci, vp, vp, vp],
     "pf_attractor": [vp, ci, ci, ci, cf, ci, ci, vp, ci, ci, vp, ci, ci, ci, ci, vp],
     "pf_seed_bin_centers": [vp, ci, vp, cl, ci, cf, cf, ci, ci, vp],
     "pf_bounded_bin_centers": [vp, vp, cl, ci, cf, cf, vp],

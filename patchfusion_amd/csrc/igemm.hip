@@ -151,8 +151,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const pf_conv_
   // so the swizzle term is the same for every pass of a thread). ----
   const int r0 = tid >> 3;                       // tile row of pass 0
   const int j = (tid & 7) ^ ((r0 >> 1) & 7);     // logical 16-byte slot within the 128-byte chunk row
-  const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
-  const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
+  // blockIdx.y = plane of a batched GEMM (pf_conv_params.batch: the (m+2)^2 transform points of a Winograd layer share one launch,
+  // so the chip sees one stream of tiles instead of (m+2)^2 launches with a tail each); the strides are 0 / unused otherwise
+  const size_t plane = blockIdx.y;
+  const T* __restrict__ xg = reinterpret_cast<const T*>(p.x) + plane * (size_t)p.x_bstride;
+  const T* __restrict__ wg = reinterpret_cast<const T*>(p.w) + plane * (size_t)p.w_bstride;
   const char* zero = reinterpret_cast<const char*>(pf_zero_page);
   const int ntaps = p.KH * p.KW;
   const char* a_ptr[A_ITERS];
@@ -396,8 +399,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const pf_conv_
 #ifdef PF_ABL_NOSTORE
       if (v[0] == 12345.678f) store4(reinterpret_cast<T*>(p.y) + opix * p.y_ld + co, v[0], v[1], v[2], v[3]);
 #else
-      if (p.out_f32) store4(reinterpret_cast<float*>(p.y) + opix * p.y_ld + co, v[0], v[1], v[2], v[3]);
-      else store4(reinterpret_cast<T*>(p.y) + opix * p.y_ld + co, v[0], v[1], v[2], v[3]);
+      if (p.out_f32) store4(reinterpret_cast<float*>(p.y) + plane * (size_t)p.y_bstride + opix * p.y_ld + co, v[0], v[1], v[2], v[3]);
+      else store4(reinterpret_cast<T*>(p.y) + plane * (size_t)p.y_bstride + opix * p.y_ld + co, v[0], v[1], v[2], v[3]);
 #endif
     }
   }
@@ -1304,7 +1307,7 @@ int launch_cfg2(const pf_conv_params& p, hipStream_t st) {
   ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
   const long M = (long)p.B * p.OH * p.OW;
   const long mt = (M + BM - 1) / BM, nt = (p.Cout + BN - 1) / BN;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(mt * nt)), dim3(64 * WM * WN), smem, st, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(mt * nt), (unsigned)(p.batch > 1 ? p.batch : 1)), dim3(64 * WM * WN), smem, st, p);
   return launch_status();
 }
 
@@ -1451,7 +1454,7 @@ int launch_generic(const pf_conv_params& p, hipStream_t st, int cfg) {
 // remainder launched with a narrower tile (544 = 5 x 96 + 64): two launches on the same stream, zero padded MFMAs.
 template <typename T>
 int dispatch_generic(const pf_conv_params& p, hipStream_t st, bool allow_split) {
-  const long M = (long)p.B * p.OH * p.OW;
+  const long M = (long)p.B * p.OH * p.OW * (p.batch > 1 ? p.batch : 1);   // cost model only: the planes of a batched GEMM are one stream of tiles
   // PF_IGEMM_CFG / PF_IGEMM_NOSPLIT are kernel-tuning overrides, read per call (a getenv is ~50 ns against a >= 2 us launch)
   const char* e = getenv("PF_IGEMM_CFG");
   const int force_cfg = e ? atoi(e) : -1;
@@ -1514,6 +1517,8 @@ int validate(const pf_conv_params* p) {
   else if ((long)p->B * p->OH * p->OW <= 0) e = "empty output";
   else if ((long)p->B * p->OH * p->OW >= (1L << 31)) e = "too many output pixels";
   else if (p->korder != 0 && (p->korder != 1 || p->dtype != PF_DTYPE_F32 || p->Cin % 32 || p->shuffle > 1)) e = "korder 1 needs f32, Cin % 32 == 0, no shuffle";
+  else if (p->batch > 1 && (p->dtype != PF_DTYPE_F32 || p->shuffle > 1 || p->res || p->res2 || p->bias || p->scale || p->batch > 65535))
+    e = "batch > 1: float32 GEMM planes without bias / scale / residual only";
   if (e) { snprintf(g_err, sizeof(g_err), "pf_conv: %s", e); return PF_ERR_ARG; }
   return PF_OK;
 }

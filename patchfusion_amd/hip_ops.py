@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from ._lib import ConvParams, check
-from .packing import PackedConv
+from .packing import PackedConv, winograd_applies
 
 _L = _lib.load()
 
@@ -82,7 +82,7 @@ class HipOps:
 
     # ---------------- conv / linear ----------------
     @staticmethod
-    def conv(x, pw: PackedConv, y, stride=1, pad=0, act=None, relu_in=False, res=None, res2=None, _timed=None):
+    def conv(x, pw: PackedConv, y, stride=1, pad=0, act=None, relu_in=False, res=None, res2=None, _timed=None, _direct=None):
         x4, y4 = _as4(x), _as4(y)
         B, H, W, _ = x4.shape
         OH = (H + 2 * pad - pw.KH) // stride + 1
@@ -109,12 +109,54 @@ class HipOps:
         p.korder = pw.korder
         for t in (x4, y4, pw.w, res, res2):
             _p(t)
-        if _timed is not None:
+        wino = winograd_applies(pw, B * H * W, stride, pad, act) and not _direct
+        if _timed is not None and not wino:
             ms = C.c_float(0)
             check(_L.pf_conv_timed(C.byref(p), int(_timed), C.byref(ms), _stream()), "pf_conv_timed")
             return ms.value
+        if wino:
+            # float32 3x3 layers with enough pixels: input transform -> (m+2)^2 GEMMs -> output transform (csrc/winograd.hip)
+            m = pw.wino_m
+            T = B * -(-H // m) * -(-W // m)
+            a2 = (m + 2) ** 2
+            assert y4.dtype == torch.float32 and (res is None or res.dtype == torch.float32) and (res2 is None or res2.dtype == torch.float32)
+            V = torch.empty(a2 * T * pw.cin, dtype=torch.float32, device=x4.device)
+            Mw = torch.empty(a2 * T * pw.cout, dtype=torch.float32, device=x4.device)
+
+            def run():
+                check(_L.pf_conv_winograd(C.byref(p), m, _p(pw.wino_u), pw.wino_u.shape[1], pw.wino_u.shape[2], _p(V), _p(Mw), _stream()),
+                      "pf_conv_winograd")
+            if _timed is None:
+                run()
+                return y
+            run()                                             # whole three-step layer, events on the launch stream
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(int(_timed)):
+                run()
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / int(_timed)
         check(_L.pf_conv(C.byref(p), _stream()), "pf_conv")
         return y
+
+    @staticmethod
+    def gemm_planes_timed(V, U, Mw, planes, T, cin, cout, iters):
+        """time the batched GEMM launch of a Winograd layer alone (bench.py roofline): `planes` x ([T, cin] . [cout, cin]^T) through
+        pf_conv with pf_conv_params.batch, exactly as csrc/winograd.hip issues it; V / Mw float32 workspaces, U [planes, rows, Kpad]"""
+        assert V.dtype == U.dtype == Mw.dtype == torch.float32 and V.numel() >= planes * T * cin and Mw.numel() >= planes * T * cout
+        p = ConvParams()
+        p.x, p.x_ld, p.B, p.H, p.W, p.Cin = V.data_ptr(), cin, 1, 1, T, cin
+        p.w, p.w_rows, p.Kpad = U.data_ptr(), U.shape[1], U.shape[2]
+        p.y, p.y_ld, p.OH, p.OW, p.Cout = Mw.data_ptr(), cout, 1, T, cout
+        p.KH = p.KW = p.stride = 1
+        p.shuffle, p.dtype = 1, 0
+        p.batch, p.x_bstride, p.w_bstride, p.y_bstride = planes, T * cin, U.shape[1] * U.shape[2], T * cout
+        for t in (V, U, Mw):
+            _p(t)
+        ms = C.c_float(0)
+        check(_L.pf_conv_timed(C.byref(p), int(iters), C.byref(ms), _stream()), "pf_conv_timed")
+        return ms.value
 
     # ---------------- ViT ----------------
     @staticmethod

@@ -31,9 +31,13 @@ class PackedConv:
     cout_real: int
     shuffle: int = 1                # s for ConvTranspose2d(kernel=stride=s)
     korder: int = 0                 # K order of `w`: 0 = (ky, kx, c) tap-major; 1 = (c / 32, ky, kx, c % 32) chunk-major
+    wino_m: int = 0                 # Winograd F(m x m, 3 x 3) output tile (2 | 4), 0 = direct kernel only
+    wino_u: Optional[torch.Tensor] = None   # [(m+2)^2, rows, Kpad1] float32: G g G^T, each plane packed like a 1x1 weight
 
     def to(self, device):
         self.w = self.w.to(device)
+        if self.wino_u is not None:
+            self.wino_u = self.wino_u.to(device)
         if self.bias is not None:
             self.bias = self.bias.to(device)
         if self.scale is not None:
@@ -43,6 +47,61 @@ class PackedConv:
 
 def k_chunk(dtype):
     return 64 if dtype == torch.bfloat16 else 32
+
+
+# Winograd transform matrices (Lavin & Gray, "Fast Algorithms for Convolutional Neural Networks"): F(2x2, 3x3) and F(4x4, 3x3) with
+# the interpolation points {0, 1, -1} / {0, 1, -1, 2, -2}; B^T and A^T live in csrc/winograd.hip, G is applied here once per layer.
+WINO_G = {
+    2: [[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]],
+    4: [[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]],
+}
+WINO_BT = {
+    2: [[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]],
+    4: [[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]],
+}
+WINO_AT = {
+    2: [[1, 1, 1, 0], [0, 1, -1, -1]],
+    4: [[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]],
+}
+
+
+def winograd_mode():
+    """F(m x m, 3 x 3) tile of the float32 mode's large 3x3 layers: PF_WINOGRAD = 0 (direct kernels only) | 2 | 4 (default: 4x fewer
+    multiplies; its float32 rounding, ~15x a direct convolution's per layer, does not show in the final depth -- DESIGN.md 4d)."""
+    import os
+    m = int(os.environ.get("PF_WINOGRAD", "4"))
+    if m not in (0, 2, 4):
+        raise ValueError("PF_WINOGRAD must be 0, 2 or 4")
+    return m
+
+
+def winograd_eligible(cout_store, cin_total, KH, KW, dtype):
+    """layers worth the three-step path: float32, 3x3, whole 128-byte channel chunks, GEMM N and K large enough for the
+    256-wide f32 tiles (the small-channel 3x3 layers stay on the direct kernel)"""
+    return dtype == torch.float32 and KH == 3 and KW == 3 and cin_total % 32 == 0 and cin_total >= 128 and cout_store % 32 == 0 and cout_store >= 128
+
+
+def winograd_applies(pc, pixels, stride, pad, act):
+    """call-time half of the eligibility: the layer was packed with Winograd filters and this call is a 3x3 / stride 1 / pad 1
+    convolution over enough pixels (PF_WINOGRAD_MIN_PIXELS, default 100000: below that the (m+2)^2 GEMMs are launch-bound) whose
+    epilogue the output transform implements (bias, ReLU, residuals)."""
+    import os
+    if pc.wino_u is None or stride != 1 or pad != 1 or act not in (None, "none", "relu"):
+        return False
+    return pixels >= int(os.environ.get("PF_WINOGRAD_MIN_PIXELS", "100000"))
+
+
+def winograd_filters(wk, m):
+    """wk [rows, 3, 3, cin_total] float32 (buffer channel layout) -> U [(m+2)^2, rows, Kpad] float32, U[i*(m+2)+j] = (G g G^T)[i][j];
+    evaluated in float64, rounded once."""
+    G = torch.tensor(WINO_G[m], dtype=torch.float64)
+    rows, _, _, cin_total = wk.shape
+    U = torch.einsum("ia,raxc,jx->ijrc", G, wk.double(), G)            # [A, A, rows, cin]
+    A = m + 2
+    Kpad = round_up(cin_total, 32)
+    out = torch.zeros(A * A, rows, Kpad, dtype=torch.float32)
+    out[:, :, :cin_total] = U.reshape(A * A, rows, cin_total).float()
+    return out.contiguous()
 
 
 def pack_conv(weight, bias=None, *, dtype, cin_map=None, cin_total=None, scale=None, bn=None, bn_eps=1e-5):
@@ -88,7 +147,9 @@ def pack_conv(weight, bias=None, *, dtype, cin_map=None, cin_total=None, scale=N
     if scale is not None:
         sp = torch.zeros(rows)
         sp[:cout] = scale.detach().float().cpu()
-    return PackedConv(wp.to(dtype).contiguous(), bp, sp, KH, KW, cin_total, cout_store, cout, korder=korder)
+    wm = winograd_mode() if (scale is None and winograd_eligible(cout_store, cin_total, KH, KW, dtype)) else 0
+    wu = winograd_filters(wk, wm) if wm else None
+    return PackedConv(wp.to(dtype).contiguous(), bp, sp, KH, KW, cin_total, cout_store, cout, korder=korder, wino_m=wm, wino_u=wu)
 
 
 def pack_conv_transpose(weight, bias, *, dtype):

@@ -10,7 +10,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import third_party as tp
-from patchfusion_amd.packing import unpack_conv
+from patchfusion_amd.packing import unpack_conv, winograd_applies
 
 
 def _as4(t):
@@ -50,6 +50,24 @@ def _conv_ref(xin, w, stride, pad):
     return F.conv2d(xin, w, None, stride=stride, padding=pad)
 
 
+def _conv_winograd_ref(xin, pw):
+    """csrc/winograd.hip in float32 torch: V = B^T d B per tile, M = U . V per transform point, Y = A^T M A (cropped to H x W)"""
+    from patchfusion_amd.packing import WINO_AT, WINO_BT
+    m = pw.wino_m
+    a = m + 2
+    Bt = torch.tensor(WINO_BT[m], dtype=torch.float32, device=xin.device)
+    At = torch.tensor(WINO_AT[m], dtype=torch.float32, device=xin.device)
+    B, C, H, W = xin.shape
+    TH, TW = -(-H // m), -(-W // m)
+    xp = F.pad(xin, (1, TW * m - W + 1, 1, TH * m - H + 1))
+    t = xp.unfold(2, a, m).unfold(3, a, m)                                            # [B, C, TH, TW, a, a]
+    V = torch.einsum("ij,bcyxjk,lk->bcyxil", Bt, t, Bt)
+    U = pw.wino_u.to(xin.device)[:, :pw.cout, :C].reshape(a, a, pw.cout, C)
+    M = torch.einsum("iloc,bcyxil->boyxil", U, V)
+    Y = torch.einsum("pi,boyxil,ql->boyxpq", At, M, At)                               # [B, N, TH, TW, m, m]
+    return Y.permute(0, 1, 2, 4, 3, 5).reshape(B, pw.cout, TH * m, TW * m)[:, :, :H, :W]
+
+
 class FakeOps:
     name = "fake"
 
@@ -63,14 +81,17 @@ class FakeOps:
         return torch.zeros(shape, dtype=dtype, device=device)
 
     @staticmethod
-    def conv(x, pw, y, stride=1, pad=0, act=None, relu_in=False, res=None, res2=None):
+    def conv(x, pw, y, stride=1, pad=0, act=None, relu_in=False, res=None, res2=None, _direct=None):
         x4, y4 = _as4(x), _as4(y)
         w = unpack_conv(pw).to(x4.device)
         xin = x4[..., :pw.cin].float().permute(0, 3, 1, 2)
         if relu_in:
             xin = F.relu(xin)
         s = pw.shuffle
-        v = _conv_ref(xin, w, stride, pad)                                           # [B, N, OH, OW]
+        if winograd_applies(pw, xin.shape[0] * xin.shape[2] * xin.shape[3], stride, pad, act) and not _direct:
+            v = _conv_winograd_ref(xin, pw)                                          # the three-step path with the PACKED filters
+        else:
+            v = _conv_ref(xin, w, stride, pad)                                       # [B, N, OH, OW]
         if s > 1:
             B, N, OH, OW = v.shape
             ct = N // (s * s)

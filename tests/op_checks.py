@@ -63,6 +63,47 @@ def _conv_case(dtype, B, H, W, cin, cout, k, stride=1, pad=0, act=None, relu_in=
     return _err(outs[0], outs[1]), _tol(dtype), f"conv B{B} {H}x{W} {cin}->{cout} k{k}"
 
 
+def conv_winograd(dt):
+    """float32 Winograd F(2x2,3x3) / F(4x4,3x3) (csrc/winograd.hip: input transform -> one batched GEMM launch over the (m+2)^2 planes
+    -> output transform + epilogue) against the DIRECT float32 convolution reference, incl. odd sizes (partial tiles), channel-slice
+    views, relu_in and residuals.  Tolerance: float32 rounding of the transforms (m = 4: ~15x a direct conv's), relative to max |y|."""
+    import os
+    old = {k: os.environ.get(k) for k in ("PF_WINOGRAD", "PF_WINOGRAD_MIN_PIXELS")}
+    errs = []
+    try:
+        os.environ["PF_WINOGRAD_MIN_PIXELS"] = "0"
+        for m in (2, 4):
+            os.environ["PF_WINOGRAD"] = str(m)
+            for i, (B, H, W, cin, cout, kw) in enumerate((
+                    (2, 37, 41, 128, 160, dict(act="relu")),
+                    (1, 64, 64, 256, 128, dict(relu_in=True, res=True, res2=True)),
+                    (1, 30, 43, 544, 544, dict()),
+                    (3, 5, 3, 128, 128, dict(act="relu", res=True)))):
+                g = torch.Generator().manual_seed(100 + i)
+                w = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+                pw = pk.pack_conv(w, torch.randn(cout, generator=g), dtype=torch.float32).to(DEV)
+                assert pw.wino_m == m and pw.wino_u is not None
+                xb = _rand((B, H, W, cin + 16), torch.float32, 200 + i)
+                x = xb[..., 8:8 + cin]
+                r1 = _rand((B, H, W, cout), torch.float32, 300 + i) if kw.get("res") else None
+                r2 = _rand((B, H, W, cout + 8), torch.float32, 400 + i)[..., :cout] if kw.get("res2") else None
+                outs = []
+                for o, direct in ((hip(), None), (ref_ops, True)):
+                    yb = torch.zeros((B, H, W, cout + 16), dtype=torch.float32, device=DEV)
+                    o.conv(x, pw, yb[..., 8:8 + cout], pad=1, act=kw.get("act"), relu_in=kw.get("relu_in", False), res=r1, res2=r2, _direct=direct)
+                    outs.append(yb)
+                errs.append(_err(outs[0], outs[1]) / (4.0 if m == 4 else 1.0))     # m = 4 budget: 4x the m = 2 one
+                assert float(outs[0][..., :8].abs().max()) == 0.0 and float(outs[0][..., 8 + cout:].abs().max()) == 0.0
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    torch.cuda.synchronize()
+    return max(errs), 8e-6, "winograd F(2,3) / F(4,3) vs direct f32"
+
+
 def conv_gemm_qkv(dt):
     return _conv_case(dt, 1, 1, 2 * 1037, 384, 1152, 1)
 
@@ -471,7 +512,7 @@ CHECKS = {
     "conv_gemm_vitl_linear_shape": conv_gemm_vitl_linear_shape, "conv_dominant_launch": conv_dominant_launch,
     "conv_transpose": conv_transpose, "patch_embed_tokens": patch_embed_tokens, "layernorm": layernorm,
     "vit_attention": vit_attention, "swin_ops": swin_ops, "resize_ops": resize_ops, "roi_ops": roi_ops,
-    "misc_ops": misc_ops, "bins_ops": bins_ops, "stitch_ops": stitch_ops,
+    "conv_winograd": conv_winograd, "misc_ops": misc_ops, "bins_ops": bins_ops, "stitch_ops": stitch_ops,
 }
-F32_ONLY = {"bins_ops", "stitch_ops"}
+F32_ONLY = {"bins_ops", "stitch_ops", "conv_winograd"}
 DTYPES = {"fp32": torch.float32, "bf16": torch.bfloat16}

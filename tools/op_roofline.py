@@ -25,7 +25,7 @@ except Exception:  # dry run on a box without the library
     hip_ops = None
 from patchfusion_amd.config import make_config  # noqa: E402
 from patchfusion_amd.model import PatchFusion  # noqa: E402
-from patchfusion_amd.packing import PackedConv  # noqa: E402
+from patchfusion_amd.packing import PackedConv, winograd_applies  # noqa: E402
 from patchfusion_amd.spec import patchfusion_spec, synthetic_state_dict  # noqa: E402
 
 HBM_PEAK = 8.0e12
@@ -66,7 +66,9 @@ def work(name, a, k):
         s = max(pw.shuffle, 1)
         opix = y4.shape[0] * (y4.shape[1] // s) * (y4.shape[2] // s)
         fl = 2.0 * opix * pw.cin * pw.KH * pw.KW * pw.cout
-        return "flop", fl, f"{tuple(x4.shape[:3])} {pw.cin}->{pw.cout} k{pw.KH} s{k.get('stride', 1)}" + (" convT" if s > 1 else "")
+        wino = winograd_applies(pw, x4.shape[0] * x4.shape[1] * x4.shape[2], k.get("stride", 1), k.get("pad", 0), k.get("act"))
+        return "flop", fl, f"{tuple(x4.shape[:3])} {pw.cin}->{pw.cout} k{pw.KH} s{k.get('stride', 1)}" + (" convT" if s > 1 else "") + \
+            (f" [winograd F{pw.wino_m}: 3 steps, rate = direct-conv FLOPs / time]" if wino else "")
     if name == "vit_attention":
         qkv, out, B, S, heads = a[:5]
         return "flop", 4.0 * B * heads * S * S * 64, f"B{B} S{S} heads{heads} (incl. qkv_split)"
@@ -215,7 +217,9 @@ def main():
         by_op[(r["op"], r["kind"])] += r["total_ms"]
     out = [f"# every kernel launch of one 4K image pass (ViT-L, P=16, process_num=8, {dtype}), each distinct call timed standalone", "",
            f"sum of standalone times: {tot:.1f} ms per image; {sum(r['launches'] for r in rows)} launches, {len(rows)} distinct (op, shape) calls.",
-           f"MFMA-bound rows: TFLOP/s vs {MFMA_PEAK[dtype] / 1e12:.1f} TF/s dense peak; HBM-bound rows: algorithmic GB/s vs 8000 GB/s.", "",
+           f"MFMA-bound rows: TFLOP/s vs {MFMA_PEAK[dtype] / 1e12:.1f} TF/s dense peak; HBM-bound rows: algorithmic GB/s vs 8000 GB/s.",
+           "Rows tagged [winograd Fm] run the three-step float32 Winograd layer (csrc/winograd.hip): their rate is the DIRECT convolution's "
+           "FLOPs over the layer time, so it can exceed the MFMA peak (the layer multiplies (m+2)^2 / (9 m^2) as often).", "",
            "## per op", "", "| op | bound | total ms / image | share |", "|---|---|---:|---:|"]
     for (op, kind), t in sorted(by_op.items(), key=lambda kv: -kv[1]):
         out.append(f"| {op} | {'MFMA' if kind == 'flop' else 'HBM'} | {t:.2f} | {100 * t / tot:.1f}% |")

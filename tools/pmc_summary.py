@@ -73,7 +73,12 @@ def main():
     h = hashlib.sha256()
     for f in ("igemm.hip", "pf_common.h"):
         h.update(open(os.path.join(ROOT, "patchfusion_amd", "csrc", f), "rb").read())
-    j = {"kernel": name, "grid": grid, "dtype": dtype, "kernel_source_sha": h.hexdigest()[:12], "dispatches_total_all_passes": len(durs), "pf_conv_calls_per_pass": 6,
+    wm = 0
+    if dtype == "fp32":
+        sys.path.insert(0, ROOT)
+        from patchfusion_amd.packing import winograd_mode
+        wm = winograd_mode()
+    j = {"kernel": name, "grid": grid, "dtype": dtype, "kernel_source_sha": h.hexdigest()[:12], "winograd_m": wm, "dispatches_total_all_passes": len(durs), "pf_conv_calls_per_pass": 6,
          "command": "rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python bench.py --roofline-only --dtype " + dtype,
          "per_launch": per, "derived": der}
     json.dump(j, open(out, "w"), indent=1)

@@ -1463,6 +1463,10 @@ int dispatch_generic(const pf_conv_params& p, hipStream_t st, bool allow_split) 
   double cost_single;
   int best = best_cfg<T>(p, M, p.Cout, &cost_single);
   if (force_cfg >= 0 && !(force_cfg == 0 && sizeof(T) != 2) && !(force_cfg >= 6 && sizeof(T) != 4)) return launch_generic<T>(p, st, force_cfg);
+  // batched planes (the transform-domain GEMMs of a Winograd layer): K is one layer's Cin (17 .. 32 chunks), so the per-tile
+  // prologue / epilogue weighs as much as the K loop -- the 128x64 tile with three blocks per CU overlaps them best on every
+  // shape measured (profiles/r2c_wino_tune.log: 118 vs 111 TF/s (cost model's split) at 544->544, 130 vs 121 at 768->768)
+  if (p.batch > 1) return launch_generic<T>(p, st, p.Cout <= 32 ? 4 : 3);
   if constexpr (sizeof(T) == 4) {
     if (allow_split && !no_split && p.shuffle <= 1 && p.Cout > 128) {
       int split_at = 0, split_cfg = -1;

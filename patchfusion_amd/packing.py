@@ -76,19 +76,19 @@ def winograd_mode():
 
 
 def winograd_eligible(cout_store, cin_total, KH, KW, dtype):
-    """layers worth the three-step path: float32, 3x3, whole 128-byte channel chunks, GEMM N and K large enough for the
-    256-wide f32 tiles (the small-channel 3x3 layers stay on the direct kernel)"""
-    return dtype == torch.float32 and KH == 3 and KW == 3 and cin_total % 32 == 0 and cin_total >= 128 and cout_store % 32 == 0 and cout_store >= 128
+    """layers worth the three-step path: float32, 3x3, whole 128-byte channel chunks on both sides, K = Cin of at least four chunks
+    (the 8 / 32 / 64-channel 3x3 layers stay on the direct kernel)"""
+    return dtype == torch.float32 and KH == 3 and KW == 3 and cin_total % 32 == 0 and cin_total >= 128 and cout_store % 32 == 0
 
 
 def winograd_applies(pc, pixels, stride, pad, act):
     """call-time half of the eligibility: the layer was packed with Winograd filters and this call is a 3x3 / stride 1 / pad 1
-    convolution over enough pixels (PF_WINOGRAD_MIN_PIXELS, default 100000: below that the (m+2)^2 GEMMs are launch-bound) whose
+    convolution over at least PF_WINOGRAD_MIN_PIXELS pixels (default 0: measured 1.4 .. 4x the direct kernel on every eligible layer of the pass, from 8x392x518 down to 1x14x19, profiles/r2c_wino_tune.log) whose
     epilogue the output transform implements (bias, ReLU, residuals)."""
     import os
     if pc.wino_u is None or stride != 1 or pad != 1 or act not in (None, "none", "relu"):
         return False
-    return pixels >= int(os.environ.get("PF_WINOGRAD_MIN_PIXELS", "100000"))
+    return pixels >= int(os.environ.get("PF_WINOGRAD_MIN_PIXELS", "0"))
 
 
 def winograd_filters(wk, m):

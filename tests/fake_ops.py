@@ -6,6 +6,8 @@ Two uses:
     oracle (no HIP kernel involved -- this is NOT a product path; the product only accepts hip_ops);
   * ``-m gpu``: the per-op reference each hand-written HIP kernel is compared against.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -88,8 +90,12 @@ class FakeOps:
         if relu_in:
             xin = F.relu(xin)
         s = pw.shuffle
-        if winograd_applies(pw, xin.shape[0] * xin.shape[2] * xin.shape[3], stride, pad, act) and not _direct:
-            v = _conv_winograd_ref(xin, pw)                                          # the three-step path with the PACKED filters
+        if (os.environ.get("PF_FAKE_WINOGRAD") == "1" and not _direct and not xin.is_cuda and
+                winograd_applies(pw, xin.shape[0] * xin.shape[2] * xin.shape[3], stride, pad, act)):
+            # opt-in for the CPU wiring tests of the Winograd path (tests/test_winograd_cpu.py, one end-to-end case): the three steps
+            # with the PACKED filters.  Everywhere else -- and always on the GPU, where this class is the CHECKER of the HIP kernels --
+            # the direct convolution is evaluated.
+            v = _conv_winograd_ref(xin, pw)
         else:
             v = _conv_ref(xin, w, stride, pad)                                       # [B, N, OH, OW]
         if s > 1:

@@ -13,6 +13,7 @@ from tests.fake_ops import ops as fake
 @pytest.fixture
 def wino_env(monkeypatch):
     def set_m(m, min_pixels=0):
+        monkeypatch.setenv("PF_FAKE_WINOGRAD", "1")
         monkeypatch.setenv("PF_WINOGRAD", str(m))
         monkeypatch.setenv("PF_WINOGRAD_MIN_PIXELS", str(min_pixels))
     return set_m
@@ -46,7 +47,8 @@ def test_eligibility(wino_env):
     assert pk.pack_conv(w, None, dtype=torch.float32).wino_u is not None
     assert pk.pack_conv(w, None, dtype=torch.bfloat16).wino_u is None                       # float32 mode only
     assert pk.pack_conv(w[:, :64], None, dtype=torch.float32).wino_u is None                # K too short
-    assert pk.pack_conv(w[:32], None, dtype=torch.float32).wino_u is None                   # N too narrow
+    assert pk.pack_conv(w[:32], None, dtype=torch.float32).wino_u is not None               # 32 output channels still pay
+    assert pk.pack_conv(w[:24], None, dtype=torch.float32).wino_u is None                   # not a whole 128-byte chunk
     assert pk.pack_conv(w[:, :, :1, :1], None, dtype=torch.float32).wino_u is None          # 1x1
     assert pk.pack_conv(w, None, dtype=torch.float32, scale=torch.ones(128)).wino_u is None
     pw = pk.pack_conv(w, None, dtype=torch.float32)
@@ -86,3 +88,44 @@ def test_three_step_path_equals_direct_convolution(wino_env, m, shape):
     y = torch.empty(B, H, W, 160)
     fake.conv(xbuf[..., :128], pw, y, pad=1)
     assert float((y - ref).abs().max() / ref.abs().max()) <= (1.5e-5 if m == 4 else 3e-6)
+
+
+@pytest.mark.parametrize("m", [2, 4])
+def test_engine_end_to_end_through_the_winograd_path(wino_env, m, golden_dir):
+    """the whole tiny pass with every eligible 3x3 layer (fusion U-Net, 256 channels) on the emulated three-step path: same
+    reference golden, same tolerance as the direct path (tests/test_engine_cpu.py)"""
+    import os
+    from patchfusion_amd.config import make_config
+    from patchfusion_amd.model import PatchFusion
+    from patchfusion_amd.spec import patchfusion_spec, synthetic_state_dict
+    wino_env(m)
+    g = np.load(os.path.join(golden_dir, "tiny_vits.npz"))
+    cfg = make_config("vits", (112, 154), (448, 616), (2, 2))
+    sd = synthetic_state_dict(patchfusion_spec(cfg), 0)
+    mod = PatchFusion(cfg, compute_dtype="fp32", ops=fake).eval()
+    mod.load_state_dict(sd, strict=True)
+    img = torch.rand(1, 3, 448, 616, generator=torch.Generator().manual_seed(1234))
+    d, _ = mod(mode="infer", image_lr=mod.resizer(img), image_hr=img, cai_mode="m1", process_num=2)
+    n_wino = sum(1 for pc in _packed(mod._engine) if pc.wino_u is not None and pc.wino_m == m)     # the engine is built on first use
+    assert n_wino >= 10, n_wino
+    ref = g["depth_m1"]
+    assert np.abs(d[0, 0].numpy() - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+
+
+def _packed(mod):
+    """every PackedConv the engine holds (walks the engine objects' attributes)"""
+    seen, out, stack = set(), [], [mod]
+    while stack:
+        o = stack.pop()
+        if id(o) in seen:
+            continue
+        seen.add(id(o))
+        if isinstance(o, pk.PackedConv):
+            out.append(o)
+        elif isinstance(o, (list, tuple)):
+            stack.extend(o)
+        elif isinstance(o, dict):
+            stack.extend(o.values())
+        elif hasattr(o, "__dict__") and not isinstance(o, torch.Tensor):
+            stack.extend(vars(o).values())
+    return out

@@ -34,3 +34,21 @@ def test_mfma_kernels_have_no_scratch(tmp_path):
     assert listing, os.listdir(tmp_path)
     n, viol = asm_lds_audit.audit(str(tmp_path / listing[0]))
     assert n >= 8 and not viol, viol[:5]
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
+def test_winograd_transform_kernels_have_no_scratch(tmp_path):
+    """the F(4x4,3x3) transforms hold a 6x6 tile of 4-channel vectors in registers (170 / 226 VGPRs): a spill would turn two
+    HBM-bound passes into scratch-bound ones without failing any numerical test"""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(ROOT, "patchfusion_amd", "csrc", "winograd.hip")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-c", src,
+                        "-o", str(tmp_path / "winograd.o"), "-Rpass-analysis=kernel-resource-usage"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    names = re.findall(r"Function Name: (\S+)", r.stderr)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+    vgprs = [int(x) for x in re.findall(r"VGPRs: (\d+)", r.stderr)]
+    assert len(names) == len(scratch) == 4, names
+    assert not any(scratch), dict(zip(names, scratch))
+    assert max(vgprs) <= 256, dict(zip(names, vgprs))

@@ -7,6 +7,12 @@ import of :mod:`patchfusion_amd.hip_ops` raises.  Build with ``python __graft_en
 import ctypes as C
 import os
 
+# Load order matters: PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64 and this library needs the SAME HIP runtime that
+# owns torch's streams and device pointers.  With torch imported first the dynamic linker resolves libpf_hip.so's libamdhip64.so.7
+# to the copy torch already loaded; dlopen-ing libpf_hip.so first would pull /opt/rocm's runtime into the process next to torch's,
+# and every launch on a torch stream then fails (seen as "pf_patch_im2col failed (status 2)" when build() ran before smoke()).
+import torch  # noqa: F401  (must precede the CDLL below)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PF_LIB_PATH") or os.path.join(_HERE, "libpf_hip.so")   # PF_LIB_PATH: kernel-tuning builds only
 

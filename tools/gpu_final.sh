@@ -17,6 +17,7 @@ cp $O/r2_pmc_dominant_fp32.json $O/r2_pmc_dominant_bf16.json profiles/ 2>/dev/nu
 rm -f $O/pmcf_*/p_kernel_trace.csv
 # 2. the whole GPU suite, then the bench line exactly as the driver runs it
 ( timeout 1200 python -m pytest tests -m gpu -q -x --durations=8 2>&1 | tail -16 ) > $O/r2f_pytest_gpu.log 2>&1
+( timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2 ) > $O/r2f_smoke.log 2>&1     # build() + smoke() in ONE process, like a driver may run them
 ( timeout 300 python bench.py --steps 5 --warmup 2 ) > $O/r2f_bench.json 2> $O/r2f_bench.err
 # 3. rocprofv3 --stats of the roofline command (average duration of the dominant kernel next to the HIP-event figure) and of a whole pass
 ( timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/proff_ro_f32 -o ro -- python bench.py --roofline-only --dtype fp32 ) > $O/r2_roofline_only_fp32.json 2> $O/proff_ro_f32.log

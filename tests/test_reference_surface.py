@@ -203,3 +203,41 @@ def test_infer_forward_with_the_reference_call_protocol(tiny):
             assert float((preds[0, 0] - tl).abs().max()) < 1e-5
             br = full[0, 0, ps[0]:, ps[1]:]
             assert float((preds[3, 0] - br).abs().max()) < 1e-5
+
+
+@needs_ref
+@pytest.mark.reference
+def test_tile_geometry_equals_the_reference_method_over_many_shapes():
+    """tiling.prepare_tile_cfg against the reference's own BaselinePretrain.prepare_tile_cfg (baseline_pretrain.py:91-119), called
+    unbound on a stand-in `self`: every key / value for a sweep of raw shapes and splits, and the same AssertionError (message included)
+    for shapes that 2 * split does not divide."""
+    import types
+
+    import numpy as np
+
+    from oracle import ref_shim
+    from patchfusion_amd import tiling
+    PF = ref_shim.import_reference()
+    rs = np.random.RandomState(0)
+    n_ok = n_bad = 0
+    for _ in range(300):
+        split = (int(rs.randint(1, 9)), int(rs.randint(1, 9)))
+        ps = (14 * int(rs.randint(2, 30)), 14 * int(rs.randint(2, 40)))
+        raw = (int(rs.randint(16, 4400)), int(rs.randint(16, 4400)))
+        if rs.rand() < 0.6:                                   # make most cases valid
+            raw = (raw[0] // (2 * split[0]) * 2 * split[0] or 2 * split[0], raw[1] // (2 * split[1]) * 2 * split[1] or 2 * split[1])
+        me = types.SimpleNamespace(patch_process_shape=ps)
+        try:
+            want = PF.prepare_tile_cfg(me, raw, split)
+        except AssertionError as e:
+            import re
+            with pytest.raises(AssertionError, match=re.escape(str(e))):
+                tiling.prepare_tile_cfg(ps, raw, split)
+            n_bad += 1
+            continue
+        got = tiling.prepare_tile_cfg(ps, raw, split)
+        assert set(got) == set(want), (set(got) ^ set(want))
+        for k in want:
+            assert tuple(np.ravel(got[k])) == tuple(np.ravel(want[k])), (k, raw, split)
+        n_ok += 1
+    assert n_ok > 100 and n_bad > 30, (n_ok, n_bad)

@@ -656,20 +656,30 @@ class BaselineOracle(Oracle):
     image_lr; target='fine' = tiles -> fine branch -> stitch (no coarse pass, no fusion).  NOTE r<N> makes N
     random_tile calls here (:404-408), not N // process_num as in PatchFusion."""
 
-    def __init__(self, cfg_branch, process_shape, image_raw_shape, split, sd, target):
+    def __init__(self, cfg_branch, process_shape, image_raw_shape, split, sd, target, core_provider=None):
         self.bcfg, self.ps, self.sd, self.target = cfg_branch, tuple(process_shape), sd, target
         self.raw, self.split = tuple(image_raw_shape), tuple(split)
+        self.provider = core_provider                      # type 'ZoeDepth': the external relative-depth core (hack_feature hook)
         self.taps = None
 
+    def _branch(self, x):
+        return any_branch_forward(self.sd, self.target + "_branch.", x, self.bcfg, self.provider)[0]
+
     def _predict(self, crops, bboxs, tile_cfg, process_num):
-        preds = [branch_forward(self.sd, self.target + "_branch.", crops[s:s + process_num], self.bcfg)[0]
-                 for s in range(0, crops.shape[0], process_num)]
+        preds = [self._branch(crops[s:s + process_num]) for s in range(0, crops.shape[0], process_num)]
         return torch.cat(preds, dim=0)
+
+    @torch.no_grad()
+    def train_forward(self, x, depth_gt, min_depth=1e-3, max_depth=80):
+        """BaselinePretrain.forward(mode='train') -- baseline_pretrain.py:347-363: the branch on the batch (image_lr for target
+        'coarse', crops_image_hr for 'fine') and SILogLoss against depth_gt / crop_depths.  Returns (loss, depth [B,1,h,w])."""
+        pred = self._branch(x)
+        return silog_loss(pred, depth_gt, min_depth, max_depth), pred
 
     @torch.no_grad()
     def infer(self, image_lr, image_hr, cai_mode="m1", process_num=4, tile_cfg=None):
         if self.target == "coarse":
-            return branch_forward(self.sd, "coarse_branch.", image_lr, self.bcfg)[0]
+            return self._branch(image_lr)
         tile_cfg = prepare_tile_cfg(self.ps, self.raw, self.split) if tile_cfg is None else \
             prepare_tile_cfg(self.ps, tile_cfg["image_raw_shape"], tile_cfg["patch_split_num"])
         dev = image_hr.device

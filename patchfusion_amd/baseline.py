@@ -19,7 +19,7 @@ from .spec import branch_spec
 class BaselinePretrain(PatchFusion):
     def __init__(self, coarse_branch, fine_branch, sigloss=None, min_depth=1e-3, max_depth=80, image_raw_shape=(2160, 3840),
                  patch_process_shape=(384, 512), patch_split_num=(4, 4), target='coarse', coarse_branch_zoe=None,
-                 compute_dtype=None, ops=None):
+                 compute_dtype=None, ops=None, core_provider=None):
         nn.Module.__init__(self)
         if target not in ('coarse', 'fine'):
             raise NotImplementedError(target)
@@ -27,12 +27,19 @@ class BaselinePretrain(PatchFusion):
         self.patch_process_shape = tuple(patch_process_shape)
         self.tile_cfg = self.prepare_tile_cfg(image_raw_shape, patch_split_num)
         self.min_depth, self.max_depth = min_depth, max_depth
+        self.sigloss_cfg = dict(sigloss) if isinstance(sigloss, dict) else None
         self.coarse_branch_cfg, self.fine_branch_cfg = AttrDict(dict(coarse_branch)), AttrDict(dict(fine_branch))
         self.branch_cfg = self.coarse_branch_cfg if target == 'coarse' else self.fine_branch_cfg
-        if self.branch_cfg.type != 'DA-ZoeDepth' or self.branch_cfg.midas_model_type not in ('vits', 'vitb', 'vitl'):
-            raise NotImplementedError("only the Depth-Anything branches are built (see DESIGN.md out of scope)")
+        # baseline_pretrain.py:67-86: 'DA-ZoeDepth' (Depth-Anything ViT core, resize multiple 14) or 'ZoeDepth' (MiDaS/BEiT core, an
+        # un-vendored torch.hub repo: supplied as `core_provider`, see engine.ExternalCoreBranchNet; resize multiple 32)
+        if self.branch_cfg.type == 'DA-ZoeDepth':
+            if self.branch_cfg.midas_model_type not in ('vits', 'vitb', 'vitl'):
+                raise NotImplementedError(self.branch_cfg.midas_model_type)
+        elif self.branch_cfg.type != 'ZoeDepth':
+            raise NotImplementedError
+        self.core_provider = core_provider
         self.prefix = f"{target}_branch."
-        self.resizer = Resizer(self.patch_process_shape[1], self.patch_process_shape[0], 14)
+        self.resizer = Resizer(self.patch_process_shape[1], self.patch_process_shape[0], 32 if self.branch_cfg.type == 'ZoeDepth' else 14)
         self.spec = OrderedDict()
         branch_spec(self.spec, self.prefix, self.branch_cfg)
         _build_param_tree(self, self.spec)
@@ -49,12 +56,16 @@ class BaselinePretrain(PatchFusion):
 
     def _ensure_engine(self):
         if self._engine is None:
-            from .engine import BranchNet
+            from .engine import BranchNet, ExternalCoreBranchNet
             sd = self.state_dict()
             dev = next(iter(sd.values())).device
             if self._ops is None and dev.type != "cuda":
                 raise RuntimeError("BaselinePretrain (MI355X engine) needs the model on a GPU: call .cuda() first")
-            self._engine = dict(branch=BranchNet(sd, self.prefix, self.branch_cfg, self.patch_process_shape, self.compute_dtype, dev))
+            if self.branch_cfg.type == 'ZoeDepth':
+                net = ExternalCoreBranchNet(sd, self.prefix, self.branch_cfg, self.patch_process_shape, self.compute_dtype, dev, self.core_provider)
+            else:
+                net = BranchNet(sd, self.prefix, self.branch_cfg, self.patch_process_shape, self.compute_dtype, dev)
+            self._engine = dict(branch=net)
             self._device, self._mask_cache, self._table_cache = dev, {}, {}
         return self._engine
 
@@ -66,10 +77,17 @@ class BaselinePretrain(PatchFusion):
     @torch.no_grad()
     def forward(self, mode, image_lr, image_hr, depth_gt=None, crop_depths=None, crops_image_hr=None, bboxs=None,
                 tile_cfg=None, cai_mode='m1', process_num=4, **kwargs):
-        if mode == 'train':
-            raise NotImplementedError("training forward is out of scope of the MI355X inference engine")
         nets = self._ensure_engine()
         ops, dev = self.ops, self._device
+        if mode == 'train':
+            # baseline_pretrain.py:347-363: the branch on the batch + SILogLoss.  FORWARD VALUE ONLY (no backward kernels), like
+            # PatchFusion.train_forward.
+            x, gt, key = (image_lr, depth_gt, 'coarse_loss') if self.target == 'coarse' else (crops_image_hr, crop_depths, 'fine_loss')
+            depth, _ = nets["branch"].forward(ops, x.contiguous().float())
+            depth = depth.unsqueeze(1)
+            loss_dict = {key: self._sigloss(depth, gt, self.sigloss_cfg)}
+            loss_dict['total_loss'] = loss_dict[key]
+            return loss_dict, {'rgb': image_lr, 'depth_pred': depth, 'depth_gt': gt}
         if self.target == 'coarse':
             depth = self.infer_forward(image_lr)
             return depth, {'rgb': image_lr, 'depth_pred': depth, 'depth_gt': depth_gt}

@@ -476,14 +476,18 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
         depth_prediction = d.unsqueeze(1)
         loss_dict = {}
         if crop_depths is not None:
-            gt = crop_depths.to(device=dev, dtype=torch.float32)
-            pred = depth_prediction
-            if tuple(gt.shape[-2:]) != tuple(pred.shape[-2:]):      # losses.py:27-28
-                pred = F.interpolate(pred, tuple(gt.shape[-2:]), mode='bilinear', align_corners=True)
-            loss_dict['sig_loss'] = ops.silog_loss(pred.contiguous(), gt.contiguous(), self.min_depth, self.max_depth,
-                                                   float(self.config.sigloss.get('beta', 0.15)) if isinstance(self.config.get('sigloss'), dict) else 0.15)
+            loss_dict['sig_loss'] = self._sigloss(depth_prediction, crop_depths, self.config.get('sigloss'))
             loss_dict['total_loss'] = loss_dict['sig_loss']
         return loss_dict, {'rgb': crops_image_hr, 'depth_pred': depth_prediction, 'depth_gt': crop_depths}
+
+    def _sigloss(self, pred, target, sigloss_cfg=None):
+        """SILogLoss.forward (losses.py:15-62) on the device: bilinear align_corners resize of the prediction when the grids differ
+        (:27-28), then the masked scale-invariant log loss (pf_silog_loss); beta from the loss config (default 0.15)."""
+        gt = target.to(device=self._device, dtype=torch.float32)
+        if tuple(gt.shape[-2:]) != tuple(pred.shape[-2:]):
+            pred = F.interpolate(pred, tuple(gt.shape[-2:]), mode='bilinear', align_corners=True)
+        beta = float(sigloss_cfg.get('beta', 0.15)) if isinstance(sigloss_cfg, dict) else 0.15
+        return self.ops.silog_loss(pred.contiguous(), gt.contiguous(), self.min_depth, self.max_depth, beta)
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()

@@ -58,3 +58,50 @@ def test_oracle_matches_reference_live(target, mode):
     random.seed(5621)
     o = pf_oracle.BaselineOracle(bc, PS, RAW, SPLIT, sd, target).infer(lr, img, mode, 2)
     assert d.shape == o.shape and (d - o).abs().max() < 1e-5
+
+
+def _train_batch(target):
+    g = torch.Generator().manual_seed(77)
+    x = torch.rand(2, 3, *PS, generator=g)
+    gt = torch.rand(2, 1, 56, 77, generator=g) * 3 + 0.2                 # coarser ground-truth grid: SILogLoss resizes the prediction
+    gt[0, 0, :5] = 0.0                                                   # invalid rows (below min_depth)
+    return x, gt
+
+
+@pytest.mark.parametrize("target", ["coarse", "fine"])
+def test_train_mode_forward_value_matches_oracle(target):
+    """baseline_pretrain.py:347-363 forward value (loss + prediction) through the engine wiring"""
+    bc, sd, _ = _setup(target)
+    m = BaselinePretrain(bc, bc, dict(type="SILogLoss"), 1e-3, 80, RAW, PS, SPLIT, target=target, ops=fake_ops).eval()
+    m.load_dict({k[len(target) + 8:]: v for k, v in sd.items()})
+    x, gt = _train_batch(target)
+    kw = dict(image_lr=x, image_hr=None, depth_gt=gt) if target == "coarse" else dict(image_lr=x, image_hr=None, crops_image_hr=x, crop_depths=gt)
+    loss, aux = m(mode="train", **kw)
+    want, pred = pf_oracle.BaselineOracle(bc, PS, RAW, SPLIT, sd, target).train_forward(x, gt)
+    assert set(loss) == {f"{target}_loss", "total_loss"} and loss["total_loss"] is loss[f"{target}_loss"]
+    assert abs(float(loss["total_loss"]) - float(want)) <= 2e-5 * max(1.0, abs(float(want)))
+    assert aux["depth_pred"].shape == pred.shape and (aux["depth_pred"] - pred).abs().max() < 2e-5
+    assert aux["rgb"] is x and aux["depth_gt"] is gt
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("target", ["coarse", "fine"])
+def test_train_mode_oracle_matches_reference_live(target):
+    if not ref_shim.reference_available():
+        pytest.skip("reference tree not present")
+    ref_shim.import_reference()
+    from estimator.models.baseline_pretrain import BaselinePretrain as RefBaseline
+    bc, sd, _ = _setup(target)
+    cfg = ref_shim._AttrDict(bc)
+    with ref_shim.in_reference_cwd():
+        m = RefBaseline(cfg, cfg, dict(type="SILogLoss"), 1e-3, 80, RAW, PS, SPLIT, target=target).eval()
+    m.load_dict({k[len(target) + 8:]: v for k, v in sd.items()})
+    x, gt = _train_batch(target)
+    with torch.no_grad():
+        if target == "coarse":
+            loss, aux = m(mode="train", image_lr=x, image_hr=None, depth_gt=gt)
+        else:
+            loss, aux = m(mode="train", image_lr=x, image_hr=None, depth_gt=None, crops_image_hr=x, crop_depths=gt)
+    want, pred = pf_oracle.BaselineOracle(bc, PS, RAW, SPLIT, sd, target).train_forward(x, gt)
+    assert abs(float(loss["total_loss"]) - float(want)) <= 1e-5 * max(1.0, abs(float(want)))
+    assert (aux["depth_pred"] - pred).abs().max() < 1e-5

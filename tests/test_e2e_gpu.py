@@ -243,3 +243,44 @@ def test_bin_center_variants_fp32_match_reference_golden(golden_dir, kind, atype
     ref = g[f"{kind}_depth_m1"]
     err = np.abs(d[0, 0].cpu().numpy() - ref).max()
     assert err <= 2e-4 * max(1.0, np.abs(ref).max()), (kind, err)
+
+
+def test_baseline_pretrain_train_mode_and_external_core_on_the_engine():
+    """BaselinePretrain on the HIP engine: `forward(mode='train')` (baseline_pretrain.py:347-363: branch + SILogLoss kernel, forward
+    value) for both targets, and a type-'ZoeDepth' fine branch (external core through the provider hook, multiple-of-32 resizer)
+    tiled with m1 -- against BaselineOracle (pinned to the reference's own BaselinePretrain, tests/test_baseline_cpu.py)."""
+    from collections import OrderedDict
+    from patchfusion_amd.baseline import BaselinePretrain
+    from patchfusion_amd.config import zoe_branch_config, zoe_midas_branch_config
+    from patchfusion_amd.spec import branch_spec
+    from tests.test_baseline_cpu import _train_batch
+    from tests.zoe_core_standin import StandInCore
+    ps, raw, split = (112, 154), (448, 616), (2, 2)
+    for target in ("coarse", "fine"):
+        bc = zoe_branch_config("vits", ps)
+        spec = OrderedDict()
+        branch_spec(spec, f"{target}_branch.", bc)
+        sd = synthetic_state_dict(spec, 0)
+        m = BaselinePretrain(bc, bc, dict(type="SILogLoss"), 1e-3, 80, raw, ps, split, target=target).eval()
+        m.load_state_dict(sd, strict=True)
+        m = m.cuda()
+        x, gt = _train_batch(target)
+        kw = dict(depth_gt=gt.cuda()) if target == "coarse" else dict(crops_image_hr=x.cuda(), crop_depths=gt.cuda())
+        loss, aux = m(mode="train", image_lr=x.cuda(), image_hr=None, **kw)
+        want, pred = pf_oracle.BaselineOracle(bc, ps, raw, split, sd, target).train_forward(x, gt)
+        assert float((aux["depth_pred"].cpu() - pred).abs().max()) < 2e-4
+        assert abs(float(loss["total_loss"]) - float(want)) < 1e-3 * max(1.0, abs(float(want))), target
+    ps, raw = (96, 128), (384, 512)
+    bc = zoe_midas_branch_config(ps)
+    spec = OrderedDict()
+    branch_spec(spec, "fine_branch.", bc)
+    sd = synthetic_state_dict(spec, 0)
+    core = StandInCore(21)
+    m = BaselinePretrain(bc, bc, None, 1e-3, 80, raw, ps, split, target="fine", core_provider=core).eval()
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    img = torch.rand(1, 3, *raw, generator=torch.Generator().manual_seed(4321))
+    lr = m.resizer(img)
+    d, _ = m(mode="infer", image_lr=lr.cuda(), image_hr=img.cuda(), cai_mode="m1", process_num=2)
+    o = pf_oracle.BaselineOracle(bc, ps, raw, split, sd, "fine", core_provider=core).infer(lr, img, "m1", 2)
+    assert d.shape == o.shape and float((d.cpu() - o).abs().max()) < 2e-4

@@ -69,3 +69,33 @@ def test_zoe_branch_features_match_oracle(zoe):
     assert float((depth - od).abs().max()) < 1e-5
     for a, b in zip(feats, of):
         assert a.shape == b.shape and float((a - b).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("target,mode", [("coarse", "m1"), ("fine", "m2"), ("fine", "r1")])
+def test_zoe_baseline_pretrain_matches_oracle_with_injected_core(target, mode):
+    """BaselinePretrain with a type-'ZoeDepth' branch (baseline_pretrain.py:67-86): multiple-of-32 resizer, external core through
+    the provider hook, the rest on the engine -- against BaselineOracle with the same stand-in core."""
+    from collections import OrderedDict
+
+    from patchfusion_amd.baseline import BaselinePretrain
+    from patchfusion_amd.config import zoe_midas_branch_config
+    from patchfusion_amd.spec import branch_spec
+    bc = zoe_midas_branch_config(PS)
+    spec = OrderedDict()
+    branch_spec(spec, f"{target}_branch.", bc)
+    sd = synthetic_state_dict(spec, 0)
+    core = StandInCore(21)
+    m = BaselinePretrain(bc, bc, dict(type="SILogLoss"), 1e-3, 80, RAW, PS, SPLIT, target=target, ops=fake_ops, core_provider=core).eval()
+    assert list(m.state_dict().keys()) == list(sd.keys()) and m.resizer.m == 32
+    m.load_dict({k[len(target) + 8:]: v for k, v in sd.items()})
+    img = torch.rand(1, 3, *RAW, generator=torch.Generator().manual_seed(4321))
+    lr = m.resizer(img)
+    random.seed(5621)
+    d, _ = m(mode="infer", image_lr=lr, image_hr=img, cai_mode=mode, process_num=2)
+    random.seed(5621)
+    o = pf_oracle.BaselineOracle(bc, PS, RAW, SPLIT, sd, target, core_provider=core).infer(lr, img, mode, 2)
+    assert d.shape == o.shape and float((d - o).abs().max()) < 2e-5
+    with pytest.raises(NotImplementedError, match="relative-depth core"):
+        b = BaselinePretrain(bc, bc, None, 1e-3, 80, RAW, PS, SPLIT, target=target, ops=fake_ops)
+        b.load_dict({k[len(target) + 8:]: v for k, v in sd.items()})
+        b(mode="infer", image_lr=lr, image_hr=img)

@@ -74,6 +74,16 @@ int pf_conv_timed(const pf_conv_params* p, int iters, float* ms, void* stream);
  * m = 2 multiplies 2.25x less than the direct convolution at ~2.5x its float32 rounding error, m = 4 4x less at ~15x. */
 int pf_conv_winograd(const pf_conv_params* p, int m, const void* U, int u_rows, int u_kpad, void* V, void* M, void* stream);
 
+/* FUSED Winograd F(4x4, 3x3) (csrc/wino_fused.hip): the same layers in ONE kernel -- the transformed input and the transform-domain
+ * products never exist in HBM.  `p` as for pf_conv_winograd (p->w is not read); `up` = the filters in MFMA fragment order
+ * [nnb][Cin/8][36][2][64][4] floats (patchfusion_amd/packing.py winograd_filters_fused), nnb = ceil(Cout/64); `gs` = strips of 32
+ * output tiles per block group (L2 locality knob, >= 1).  Needs Cin % 8 == 0, Cout % 4 == 0, W >= 29, B*H*W*x_ld < 2^31:
+ * pf_conv_winograd_fused_supported(p) returns 1 when `p` qualifies, else 0 (callers then take pf_conv_winograd / pf_conv). */
+int pf_conv_winograd_fused_supported(const pf_conv_params* p);
+int pf_conv_winograd_fused(const pf_conv_params* p, const void* up, int nnb, int gs, void* stream);
+/* timing helper like pf_conv_timed: `iters` launches bracketed by HIP events on `stream` */
+int pf_conv_winograd_fused_timed(const pf_conv_params* p, const void* up, int nnb, int gs, int iters, float* ms, void* stream);
+
 /* ---- ViT encoder pieces ---------------------------------------------------------------------- */
 /* (x - mean)/std + 14x14/14 patch gather: NCHW float image -> im2col rows [B*th*tw][ld] (K order
  * ky,kx,c).  Replaces depth_anything.py:184-190 (Normalize) + the unfold implied by patch_embed.py:76 */

@@ -54,6 +54,8 @@ SIGNATURES = {
     "pf_pack_fusion_input": [vp, vp, vp, vp, ci, ci, ci, ci, vp],
     "pf_nhwc_to_nchw_f32": [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp],
     "pf_conv_winograd": [C.POINTER(ConvParams), ci, vp, ci, ci, vp, vp, vp],
+    "pf_conv_winograd_fused": [C.POINTER(ConvParams), vp, ci, ci, vp],
+    "pf_conv_winograd_fused_timed": [C.POINTER(ConvParams), vp, ci, ci, ci, C.POINTER(cf), vp],
     "pf_attractor": [vp, ci, ci, ci, cf, ci, ci, vp, ci, ci, vp, ci, ci, ci, ci, vp],
     "pf_seed_bin_centers": [vp, ci, vp, cl, ci, cf, cf, ci, ci, vp],
     "pf_bounded_bin_centers": [vp, vp, cl, ci, cf, cf, vp],
@@ -71,7 +73,7 @@ SIGNATURES = {
     "pf_silog_loss": [vp, vp, cl, cf, cf, cf, vp, vp, vp],
     "pf_depth_metrics": [vp, ci, ci, vp, ci, ci, vp, vp, cf, cf, ci, ci, ci, ci, vp, vp],
 }
-NON_STATUS = ("pf_last_error", "pf_version", "pf_percentile_workspace_bytes")   # entry points that do not return a status
+NON_STATUS = ("pf_last_error", "pf_version", "pf_percentile_workspace_bytes", "pf_conv_winograd_fused_supported")   # entry points that do not return a status
 
 _lib = None
 
@@ -96,6 +98,8 @@ def load():
     lib.pf_version.argtypes = []
     lib.pf_percentile_workspace_bytes.restype = ci
     lib.pf_percentile_workspace_bytes.argtypes = []
+    lib.pf_conv_winograd_fused_supported.restype = ci          # 1 / 0, not a status
+    lib.pf_conv_winograd_fused_supported.argtypes = [C.POINTER(ConvParams)]
     _lib = lib
     return lib
 

@@ -1,0 +1,517 @@
+// Fully fused Winograd F(4x4, 3x3) convolution for the float32 ("exact") mode -- ONE kernel per layer: the transformed input V
+// and the transform-domain products M of csrc/winograd.hip's three-step path never exist in HBM.
+// Same reference layers: 3x3 / stride 1 / pad 1 convolutions of the guided-fusion U-Net and the DPT head
+// (estimator/models/blocks/guided_fusion_model.py:41-48,85-100,129; external/depth_anything/blocks.py:69-92, dpt.py:87-90).
+//
+//   Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A
+//
+// Work decomposition.  A block owns a STRIP of 32 consecutive 4x4 output tiles (flattened (b, ty, tx) order, so only the 4-pixel tile
+// rounding of W is padding) x 64 output channels x ALL 36 transform points; it walks Cin in chunks of 8 channels:
+//   raw   : the strip's 6-row input halo of one chunk, brought by LDS-DMA (global_load_lds_dwordx4) into a 2-deep ring,
+//           layout [row a 0..5][channel quad h 0..1][column x 0..137][4 ch]  (16-byte slots = the DMA granule)
+//   V     : B^T d B of that chunk, [36 planes][32 tiles][8 ch] float, 2-deep; written by the four "transform" waves from raw
+//   MFMA  : wave (pg, half) multiplies planes 9 pg .. 9 pg + 8 for output channels n0 + 32 half .. + 31:
+//           D[n][tile] += U_plane[n][c] V_plane[tile][c] on v_mfma_f32_16x16x4_f32 (A = filters, B = tiles), 144 accumulator
+//           registers per lane; the filter fragments come straight from global memory (L2) into registers in a pre-packed
+//           fragment order (packing.winograd_filters_fused) -- no other wave needs them, so staging them in LDS would buy nothing --
+//           as a rolling prefetch: plane p's registers are reloaded for the NEXT chunk right after its last MFMA of this chunk.
+//   out   : after the last chunk the 36 planes of a (tile, 4-channel) unit sit in four different waves; they are exchanged through
+//           LDS once (one channel half at a time: 36 x 32 x 32 floats = 144 KiB), A^T M A + bias / ReLU / residual(s) run in registers
+//           and y is stored once.
+// Per 8-channel chunk a block issues 576 MFMAs (4608 cycles per SIMD) against 26 KiB of input halo and 72 KiB of filter fragments.
+//
+// Wave roles (8 waves, two per SIMD: wave w and w+4).  Waves 0-3 ("transform", channel half 0): planes 0-3, the input transform of
+// the next chunk (VALU + LDS only), planes 4-8.  Waves 4-7 ("DMA", channel half 1): the 28 LDS-DMA pieces of the chunk after next
+// first, then planes 0-8.  The two waves of a SIMD are therefore never both outside their MFMA stream.
+// One barrier per chunk.  Global loads and the DMA are issued from inline asm and counted by hand (s_waitcnt vmcnt(N) naming the
+// registers it releases, like the hand-counted LDS reads of igemm.hip); tools/asm_vm_audit.py replays the in-order VMEM queue over the
+// emitted assembly (tests/test_kernel_resources.py).
+#include <atomic>
+#include "pf_common.h"
+#include "../../include/pf_hip.h"
+
+namespace {
+
+constexpr int NT = 32;                        // tiles per strip
+constexpr int RC = 138;                       // raw columns per (row, quad) plane: 4*32 + 2*5 segments; RC*4 % 32 == 8 (bank spread of h)
+constexpr int RAW_SLOTS = 6 * 2 * RC;         // 1656 16-byte slots
+constexpr int DMA_PIECES = 28;                // 1 KiB each, 7 per DMA wave
+constexpr int RAW_STAGE = DMA_PIECES * 1024;  // 28672
+constexpr int V_STAGE = 36 * NT * 8 * 4;      // 36864
+constexpr int LDS_V0 = 2 * RAW_STAGE;         // 57344
+constexpr int LDS_MAIN = LDS_V0 + 2 * V_STAGE;   // 131072
+constexpr int LDS_EPI = 36 * NT * 8 * 16;     // 147456: [36][32 tiles][8 quads] float4 = one channel half of M
+constexpr int LDS_TAB = LDS_EPI;              // column table behind everything: colbase[144], colty[144]
+constexpr int LDS_TOTAL = LDS_TAB + 2 * 144 * 4;
+constexpr int U_PLANE = 2 * 1024;             // bytes between planes of the packed filters (2 halves x 64 lanes x 16 B)
+constexpr int U_CHUNK = 36 * U_PLANE;         // bytes between 8-channel chunks
+static_assert(LDS_MAIN <= LDS_EPI && LDS_TOTAL <= 160 * 1024, "LDS budget");
+static_assert((RC * 4) % 32 == 8 && RAW_SLOTS <= DMA_PIECES * 64, "raw layout");
+
+struct WF {
+  const float* x; int x_ld; int B, H, W, Cin;
+  const float* up;
+  float* y; int y_ld; int Cout;
+  const float* bias; int relu; int relu_in;
+  const float* res; int res_ld; const float* res2; int res2_ld;
+  int TH, TW, T, nstrips, nnb, nkc, gs;
+};
+
+__device__ __attribute__((aligned(256))) unsigned int wf_zero_page[64];
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+// LDS-DMA of 16 bytes per lane (see igemm.hip glds16; cdna_hip_programming.md 5.7)
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+// global -> register load hipcc does not see (no s_waitcnt bookkeeping): the destination is tied ("+v") so that the register
+// stays ONE live range through the chunk loop; vm_wait<N> names it again before the first MFMA that reads it.
+__device__ __forceinline__ void gload16(f32x4& dst, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(dst) : "v"(p));
+}
+template <int N>
+__device__ __forceinline__ void vm_wait(f32x4& a) {
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void vm_wait_plain() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() is fence + barrier, and the fence may be lowered
+// to vmcnt(0): that would drain the filter prefetch and the DMA that are meant to stay in flight across the barrier.
+// The TAG (an assembler comment) keeps the barriers of the two wave roles textually different, so that hipcc does not merge the
+// two role paths at a shared barrier: each role's accumulators must be dead once that role has written them to LDS.
+template <int TAG = 0>
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier ; role tag %0" ::"n"(TAG) : "memory");
+}
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]   (same formulas as winograd.hip)
+__device__ __forceinline__ void bt6(float (&d)[6]) {
+  const float o0 = 4.f * d[0] - 5.f * d[2] + d[4];
+  const float o1 = -4.f * (d[1] + d[2]) + d[3] + d[4];
+  const float o2 = 4.f * (d[1] - d[2]) - d[3] + d[4];
+  const float o3 = -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
+  const float o4 = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
+  const float o5 = 4.f * d[1] - 5.f * d[3] + d[5];
+  d[0] = o0; d[1] = o1; d[2] = o2; d[3] = o3; d[4] = o4; d[5] = o5;
+}
+// A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+__device__ __forceinline__ void at6(const float (&m)[6], float (&o)[4]) {
+  const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+  o[0] = m[0] + s12 + s34;
+  o[1] = d12 + 2.f * d34;
+  o[2] = s12 + 4.f * s34;
+  o[3] = d12 + 8.f * d34 + m[5];
+}
+
+// input transform of one (tile, channel) unit: 36 LDS reads at raw + (a*2*RC + b)*16, B^T d B, 36 LDS writes at vout + k*1024
+__device__ __forceinline__ void transform_unit(const char* raw, char* vout, float lo) {
+  float d[6][6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b < 6; ++b) d[a][b] = fmaxf(*reinterpret_cast<const float*>(raw + (a * 2 * RC + b) * 16), lo);
+#pragma unroll
+  for (int b = 0; b < 6; ++b) {                     // B^T d : down the columns
+    float col[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) col[a] = d[a][b];
+    bt6(col);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) d[a][b] = col[a];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {                     // (B^T d) B : along the rows
+    bt6(d[i]);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) *reinterpret_cast<float*>(vout + (i * 6 + j) * 1024) = d[i][j];
+  }
+}
+
+__global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pg = wave & 3, half = wave >> 2;
+  const unsigned smem_base = lds_addr(smem);
+
+  // ---- block -> (strip, channel block): groups of `gs` strips x all channel blocks, strips fastest (consecutive ids share an XCD:
+  // its ~32 resident blocks are gs strips x a few channel blocks whose filter streams overlap in L2, and the strips' input halos are
+  // re-read by the other channel blocks of the group while they are still L2 / MALL resident) ----
+  int strip, nb;
+  {
+    const int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int per_group = p.gs * p.nnb;
+    const int group = bid / per_group;
+    const int first = group * p.gs;
+    const int gsz = min(p.nstrips - first, p.gs);
+    const int in_g = bid - group * per_group;
+    nb = in_g / gsz;
+    strip = first + (in_g - nb * gsz);
+  }
+  const int T0 = strip * NT;
+  const int THW = p.TH * p.TW;
+  const int tx0 = T0 % p.TW;
+  const int n0 = nb * 64;
+  const bool active = n0 + half * 32 < p.Cout;          // (wave-uniform) this wave's 32 output channels exist
+
+  // ---- column table: raw column x -> (pixel index of (b, row 0, ix) or -1, tile row ty).  Tile slot s of the strip owns raw columns
+  // 4 s + 2 g(s) .. + 5, g(s) = number of tile-row wraps before slot s; neighbours of one tile row share two columns ----
+  int* colbase = reinterpret_cast<int*>(smem + LDS_TAB);
+  int* colty = colbase + 144;
+  if (tid < 144) { colbase[tid] = -1; colty[tid] = 0; }
+  __syncthreads();
+  if (tid < NT && T0 + tid < p.T) {
+    const int t = T0 + tid;
+    const int b = t / THW, rem = t - b * THW;
+    const int ty = rem / p.TW, tx = rem - ty * p.TW;
+    const int c0 = 4 * tid + 2 * ((tx0 + tid) / p.TW);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int ix = 4 * tx - 1 + j;
+      colbase[c0 + j] = (ix >= 0 && ix < p.W) ? b * p.H * p.W + ix : -1;
+      colty[c0 + j] = ty;
+    }
+  }
+  __syncthreads();
+
+  // ---- DMA lanes (waves 4-7): piece 7 pg + i, slot = piece*64 + lane -> (a, h, x); element offset of the 4 channels or -1 ----
+  int doff[7];
+  if (half) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int slot = (7 * pg + i) * 64 + lane;
+      doff[i] = -1;
+      if (slot < RAW_SLOTS) {
+        const int a = slot / (2 * RC), rem = slot - a * (2 * RC);
+        const int h = rem / RC, xc = rem - h * RC;
+        const int cb = colbase[xc], iy = 4 * colty[xc] - 1 + a;
+        if (cb >= 0 && iy >= 0 && iy < p.H) doff[i] = (cb + iy * p.W) * p.x_ld + 4 * h;
+      }
+    }
+  }
+  const char* zero = reinterpret_cast<const char*>(wf_zero_page);
+  const float* __restrict__ xg = p.x;
+  auto dma = [&](int chunk, int stage) {
+    const unsigned dst = smem_base + stage * RAW_STAGE + (7 * pg) * 1024;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const char* src = doff[i] >= 0 ? reinterpret_cast<const char*>(xg + (long)doff[i] + chunk * 8) : zero;
+      glds16(src, dst + i * 1024);
+    }
+  };
+
+  // ---- transform lanes (waves 0-3): unit = (tile slot 8 pg + lane/8, channel lane%8) ----
+  const int tc = lane & 7, tsl = 8 * pg + (lane >> 3);
+  const int t_rd = ((((tc >> 2) * RC + 4 * tsl + 2 * ((tx0 + tsl) / p.TW)) * 4) + (tc & 3)) * 4;
+  const int t_wr = (64 * pg + lane) * 4;
+  const float lo = p.relu_in ? 0.f : -INFINITY;
+
+  // ---- MFMA lanes: B fragment (tile r, channels 2 g4, 2 g4 + 1) of plane 9 pg + P, tile group tg ----
+  const int r = lane & 15, g4 = lane >> 4;
+  const int b_rd = (r * 8 + 2 * g4) * 4 + 9 * pg * 1024;
+  const char* ubase = reinterpret_cast<const char*>(p.up) + ((((long)nb * p.nkc) * 36 + 9 * pg) * 2 + half) * 1024 + lane * 16;
+
+  f32x4 acc[9][2][2];
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[i][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 u[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) u[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // one plane P with its filter fragment in u[S] and its B fragments already in BC0 / BC1: request the B fragments of plane P+1 (so their
+  // LDS latency hides behind this plane's MFMAs), wait for the filter fragment, 8 MFMAs (4 accumulators x 2 k-steps; consecutive MFMAs
+  // hit different accumulators: 40-cycle dependent latency against the 32-cycle issue), then reload u[S] from NEXT
+#define WF_BLOAD(P, B0, B1)                                                                              \
+  B0 = *reinterpret_cast<const float2*>(vcur + (P) * 1024);                                              \
+  B1 = *reinterpret_cast<const float2*>(vcur + (P) * 1024 + 512);
+#define WF_PLANE_(P, S, WAITN, NEXT, BC0, BC1, PREFETCH)                                                 \
+  {                                                                                                      \
+    PREFETCH                                                                                             \
+    vm_wait<WAITN>(u[S]);                                                                                \
+    acc[P][0][0] = mfma4(u[S][0], BC0.x, acc[P][0][0]);                                                  \
+    acc[P][1][0] = mfma4(u[S][0], BC1.x, acc[P][1][0]);                                                  \
+    acc[P][0][1] = mfma4(u[S][2], BC0.x, acc[P][0][1]);                                                  \
+    acc[P][1][1] = mfma4(u[S][2], BC1.x, acc[P][1][1]);                                                  \
+    acc[P][0][0] = mfma4(u[S][1], BC0.y, acc[P][0][0]);                                                  \
+    acc[P][1][0] = mfma4(u[S][1], BC1.y, acc[P][1][0]);                                                  \
+    acc[P][0][1] = mfma4(u[S][3], BC0.y, acc[P][0][1]);                                                  \
+    acc[P][1][1] = mfma4(u[S][3], BC1.y, acc[P][1][1]);                                                  \
+    NEXT;                                                                                                \
+  }
+  // even planes hold their B fragments in (be0, be1), odd planes in (bo0, bo1)
+#define WF_PLANE(P, S, WAITN, NEXT) WF_PLANE_E##P(P, S, WAITN, NEXT)
+#define WF_PLANE_E0(P, S, W, N) WF_PLANE_(P, S, W, N, be0, be1, WF_BLOAD(1, bo0, bo1))
+#define WF_PLANE_E1(P, S, W, N) WF_PLANE_(P, S, W, N, bo0, bo1, WF_BLOAD(2, be0, be1))
+#define WF_PLANE_E2(P, S, W, N) WF_PLANE_(P, S, W, N, be0, be1, WF_BLOAD(3, bo0, bo1))
+#define WF_PLANE_E3(P, S, W, N) WF_PLANE_(P, S, W, N, bo0, bo1, WF_BLOAD(4, be0, be1))
+#define WF_PLANE_E4(P, S, W, N) WF_PLANE_(P, S, W, N, be0, be1, WF_BLOAD(5, bo0, bo1))
+#define WF_PLANE_E5(P, S, W, N) WF_PLANE_(P, S, W, N, bo0, bo1, WF_BLOAD(6, be0, be1))
+#define WF_PLANE_E6(P, S, W, N) WF_PLANE_(P, S, W, N, be0, be1, WF_BLOAD(7, bo0, bo1))
+#define WF_PLANE_E7(P, S, W, N) WF_PLANE_(P, S, W, N, bo0, bo1, WF_BLOAD(8, be0, be1))
+#define WF_PLANE_E8(P, S, W, N) WF_PLANE_(P, S, W, N, be0, be1, )
+  float2 be0, be1, bo0, bo1;
+#define WF_NONE ((void)0)
+
+  // ---- epilogue: exchange one channel half at a time through LDS [36][32 tiles][8 quads ^ (tile & 7)] float4 ----
+  auto epi_write = [&]() {
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+      for (int tg = 0; tg < 2; ++tg)
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg)
+          *reinterpret_cast<f32x4*>(smem + ((((9 * pg + i) * 32 + tg * 16 + r) * 8) + ((cg * 4 + g4) ^ (r & 7))) * 16) = acc[i][tg][cg];
+  };
+  auto epi_out = [&]() {
+    // this lane's unit: tile group pg/2, channel group pg%2 -> tile T0 + 16 (pg/2) + r, channels n .. n+3
+    const int tl = (pg >> 1) * 16 + r;
+    const int q = ((pg & 1) * 4 + g4) ^ (r & 7);
+    const int n = n0 + half * 32 + (pg & 1) * 16 + 4 * g4;
+    const char* mp = smem + (tl * 8 + q) * 16;
+    float tcol[4][6][4];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      f32x4 m[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) m[i] = *reinterpret_cast<const f32x4*>(mp + (i * 6 + j) * (32 * 8 * 16));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float col[6] = {m[0][e], m[1][e], m[2][e], m[3][e], m[4][e], m[5][e]};
+        float o[4];
+        at6(col, o);
+#pragma unroll
+        for (int po = 0; po < 4; ++po) tcol[po][j][e] = o[po];
+      }
+      __builtin_amdgcn_sched_barrier(0);      // keep hipcc from hoisting all 36 reads (144 registers) above the first column
+    }
+    const int tile = T0 + tl;
+    if (tile >= p.T || n >= p.Cout) return;
+    const int b = tile / THW, rem = tile - b * THW;
+    const int ty = rem / p.TW, tx = rem - ty * p.TW;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n);
+    const float be[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+    for (int po = 0; po < 4; ++po) {
+      const int oy = 4 * ty + po;
+      float o[4][4];                                   // [channel e][column qo]
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float row[6] = {tcol[po][0][e], tcol[po][1][e], tcol[po][2][e], tcol[po][3][e], tcol[po][4][e], tcol[po][5][e]};
+        at6(row, o[e]);
+      }
+      if (oy >= p.H) continue;
+#pragma unroll
+      for (int qo = 0; qo < 4; ++qo) {
+        const int ox = 4 * tx + qo;
+        if (ox >= p.W) continue;
+        const long pix = ((long)b * p.H + oy) * p.W + ox;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = o[e][qo] + be[e];
+          if (p.relu) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (p.res) {
+          const float4 a = *reinterpret_cast<const float4*>(p.res + pix * p.res_ld + n);
+          v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+        }
+        if (p.res2) {
+          const float4 a = *reinterpret_cast<const float4*>(p.res2 + pix * p.res2_ld + n);
+          v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+        }
+        *reinterpret_cast<float4*>(p.y + pix * p.y_ld + n) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  };
+  const int nkc = p.nkc;
+  if (!half) {
+    // ================= transform waves: filter fragments in a 3-deep ring (u[P % 3]); plane P's fragment is requested right after
+    // plane P-3 and waited for with exactly two younger loads in flight (vmcnt(2)) =================
+    gload16(u[0], ubase);
+    gload16(u[1], ubase + U_PLANE);
+    gload16(u[2], ubase + 2 * U_PLANE);
+    vm_wait<0>(u[0]); vm_wait<0>(u[1]); vm_wait<0>(u[2]);
+    lds_barrier<1>();                                         // raw chunks 0, 1 have landed (the DMA waves waited for them)
+    transform_unit(smem + t_rd, smem + LDS_V0 + t_wr, lo);
+    lds_barrier<1>();
+    for (int c = 0; c < nkc - 1; ++c) {
+      const char* vcur = smem + LDS_V0 + (c & 1) * V_STAGE + b_rd;
+      const char* uc = ubase + (long)c * U_CHUNK;
+      WF_BLOAD(0, be0, be1)
+      WF_PLANE(0, 0, 2, gload16(u[0], uc + 3 * U_PLANE))
+      WF_PLANE(1, 1, 2, gload16(u[1], uc + 4 * U_PLANE))
+      WF_PLANE(2, 2, 2, gload16(u[2], uc + 5 * U_PLANE))
+      WF_PLANE(3, 0, 2, gload16(u[0], uc + 6 * U_PLANE))
+      transform_unit(smem + ((c + 1) & 1) * RAW_STAGE + t_rd, smem + LDS_V0 + ((c + 1) & 1) * V_STAGE + t_wr, lo);
+      WF_PLANE(4, 1, 2, gload16(u[1], uc + 7 * U_PLANE))
+      WF_PLANE(5, 2, 2, gload16(u[2], uc + 8 * U_PLANE))
+      WF_PLANE(6, 0, 2, gload16(u[0], uc + U_CHUNK))
+      WF_PLANE(7, 1, 2, gload16(u[1], uc + U_CHUNK + U_PLANE))
+      WF_PLANE(8, 2, 2, gload16(u[2], uc + U_CHUNK + 2 * U_PLANE))
+      lds_barrier<1>();
+    }
+    {
+      const char* vcur = smem + LDS_V0 + ((nkc - 1) & 1) * V_STAGE + b_rd;
+      const char* uc = ubase + (long)(nkc - 1) * U_CHUNK;
+      WF_BLOAD(0, be0, be1)
+      WF_PLANE(0, 0, 2, gload16(u[0], uc + 3 * U_PLANE))
+      WF_PLANE(1, 1, 2, gload16(u[1], uc + 4 * U_PLANE))
+      WF_PLANE(2, 2, 2, gload16(u[2], uc + 5 * U_PLANE))
+      WF_PLANE(3, 0, 2, gload16(u[0], uc + 6 * U_PLANE))
+      WF_PLANE(4, 1, 2, gload16(u[1], uc + 7 * U_PLANE))
+      WF_PLANE(5, 2, 2, gload16(u[2], uc + 8 * U_PLANE))
+      WF_PLANE(6, 0, 2, WF_NONE)
+      WF_PLANE(7, 1, 1, WF_NONE)
+      WF_PLANE(8, 2, 0, WF_NONE)
+    }
+    lds_barrier<1>();                                      // every wave has finished reading V; no DMA is in flight
+    epi_write();                                           // channel half 0 first
+    lds_barrier<1>();
+    epi_out();
+    lds_barrier<1>();
+    lds_barrier<1>();
+  } else {
+    // ================= DMA waves: all nine fragments of a chunk stay in registers; plane P's is re-requested for the next chunk right
+    // after its last MFMA.  VMEM queue when plane P waits: [u_c(P), u_c(P+1..8), DMA(c) x 7, u_{c+1}(0..P-1)] -> 15 younger
+    // (DMA(c-1) was issued before u_c(P)) =================
+    dma(0, 0);
+    dma(1, 1);
+    if (active) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) gload16(u[i], ubase + i * U_PLANE);
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) vm_wait<0>(u[i]);
+    lds_barrier<2>();
+    lds_barrier<2>();
+    if (active) {
+      for (int c = 0; c < nkc - 1; ++c) {
+        const char* vcur = smem + LDS_V0 + (c & 1) * V_STAGE + b_rd;
+        const char* un = ubase + (long)(c + 1) * U_CHUNK;
+        dma(min(c + 2, nkc - 1), c & 1);   // raw chunk c+2 -> the stage chunk c was transformed from (a harmless re-load at the end)
+        WF_BLOAD(0, be0, be1)
+        WF_PLANE(0, 0, 15, gload16(u[0], un))
+        WF_PLANE(1, 1, 15, gload16(u[1], un + 1 * U_PLANE))
+        WF_PLANE(2, 2, 15, gload16(u[2], un + 2 * U_PLANE))
+        WF_PLANE(3, 3, 15, gload16(u[3], un + 3 * U_PLANE))
+        WF_PLANE(4, 4, 15, gload16(u[4], un + 4 * U_PLANE))
+        WF_PLANE(5, 5, 15, gload16(u[5], un + 5 * U_PLANE))
+        WF_PLANE(6, 6, 15, gload16(u[6], un + 6 * U_PLANE))
+        WF_PLANE(7, 7, 15, gload16(u[7], un + 7 * U_PLANE))
+        WF_PLANE(8, 8, 15, gload16(u[8], un + 8 * U_PLANE))
+        vm_wait_plain<9>();                // DMA(c) has landed: only the nine reloads are younger
+        lds_barrier<2>();
+      }
+    } else {
+      // the upper channel half does not exist (last channel block of a layer with Cout % 64 == 32): this wave only feeds the DMA
+      for (int c = 0; c < nkc - 1; ++c) {
+        dma(min(c + 2, nkc - 1), c & 1);
+        vm_wait_plain<0>();
+        lds_barrier<2>();
+      }
+    }
+    {
+      const char* vcur = smem + LDS_V0 + ((nkc - 1) & 1) * V_STAGE + b_rd;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) vm_wait<0>(u[i]);     // every fragment of the last chunk and the last DMA
+      if (active) {
+        WF_BLOAD(0, be0, be1)
+        WF_PLANE(0, 0, 0, WF_NONE) WF_PLANE(1, 1, 0, WF_NONE) WF_PLANE(2, 2, 0, WF_NONE) WF_PLANE(3, 3, 0, WF_NONE)
+        WF_PLANE(4, 4, 0, WF_NONE) WF_PLANE(5, 5, 0, WF_NONE) WF_PLANE(6, 6, 0, WF_NONE) WF_PLANE(7, 7, 0, WF_NONE)
+        WF_PLANE(8, 8, 0, WF_NONE)
+      }
+    }
+    lds_barrier<2>();
+    lds_barrier<2>();
+    lds_barrier<2>();
+    if (active) epi_write();                               // channel half 1
+    lds_barrier<2>();
+    if (active) epi_out();
+  }
+#undef WF_PLANE
+#undef WF_PLANE_
+#undef WF_BLOAD
+#undef WF_NONE
+}
+
+std::atomic<unsigned long long> g_attr_done{0};
+
+int launch(const pf_conv_params* p, const void* up, int nnb, int gs, hipStream_t st) {
+  WF a;
+  a.x = static_cast<const float*>(p->x); a.x_ld = p->x_ld; a.B = p->B; a.H = p->H; a.W = p->W; a.Cin = p->Cin;
+  a.up = static_cast<const float*>(up);
+  a.y = static_cast<float*>(p->y); a.y_ld = p->y_ld; a.Cout = p->Cout;
+  a.bias = p->bias; a.relu = p->act == PF_ACT_RELU ? 1 : 0; a.relu_in = p->relu_in;
+  a.res = static_cast<const float*>(p->res); a.res_ld = p->res_ld;
+  a.res2 = static_cast<const float*>(p->res2); a.res2_ld = p->res2_ld;
+  a.TH = (p->H + 3) / 4; a.TW = (p->W + 3) / 4;
+  const long T = (long)p->B * a.TH * a.TW;
+  a.T = (int)T;
+  a.nstrips = (int)((T + NT - 1) / NT);
+  a.nnb = nnb;
+  a.nkc = p->Cin / 8;
+  a.gs = gs < 1 ? 1 : gs;
+  int dev = 0;
+  hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(g_attr_done.load(std::memory_order_acquire) & bit)) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    g_attr_done.fetch_or(bit, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(wino_fused_kernel, dim3((unsigned)((long)a.nstrips * nnb)), dim3(512), LDS_TOTAL, st, a);
+  return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int pf_conv_winograd_fused_supported(const pf_conv_params* p) {
+  if (!p || p->dtype != PF_DTYPE_F32 || p->KH != 3 || p->KW != 3 || p->stride != 1 || p->pad != 1 || p->shuffle > 1 || p->scale) return 0;
+  if (p->OH != p->H || p->OW != p->W || p->Cin % 8 || p->Cin < 16 || p->Cout % 4 || p->Cout <= 0) return 0;
+  if (p->act != PF_ACT_NONE && p->act != PF_ACT_RELU) return 0;
+  if (p->W < 29) return 0;                                               // at least 8 tiles per tile row (<= 5 row segments per strip)
+  if (p->x_ld % 4 || p->y_ld % 4 || (p->res && p->res_ld % 4) || (p->res2 && p->res2_ld % 4)) return 0;
+  const long pix = (long)p->B * p->H * p->W;
+  if (pix * p->x_ld >= (1L << 31) || (long)p->B * ((p->H + 3) / 4) * ((p->W + 3) / 4) >= (1L << 31)) return 0;
+  return 1;
+}
+
+extern "C" int pf_conv_winograd_fused(const pf_conv_params* p, const void* up, int nnb, int gs, void* stream) {
+  if (!p || !up || !p->x || !p->y) return PF_ERR_ARG;
+  if (!pf_conv_winograd_fused_supported(p) || nnb != (p->Cout + 63) / 64) return PF_ERR_ARG;
+  return launch(p, up, nnb, gs, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int pf_conv_winograd_fused_timed(const pf_conv_params* p, const void* up, int nnb, int gs, int iters, float* ms, void* stream) {
+  if (!ms || iters <= 0) return PF_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int rc = pf_conv_winograd_fused(p, up, nnb, gs, stream);   // warm-up
+  if (rc != PF_OK) return rc;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipEventRecord(e0, st);
+  for (int i = 0; i < iters && rc == PF_OK; ++i) rc = pf_conv_winograd_fused(p, up, nnb, gs, stream);
+  hipEventRecord(e1, st);
+  hipEventSynchronize(e1);
+  float t = 0.f;
+  hipEventElapsedTime(&t, e0, e1);
+  *ms = t / iters;
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  return rc;
+}

@@ -234,13 +234,14 @@ class BranchNet:
                 feats.append(f)
         return feats
 
-    def forward(self, ops, img, taps=None):
+    def forward(self, ops, img, taps=None, vit_feats=None):
         """img [B,3,H,W] float32 in [0,1] -> (depth f32 [B,H,W], feats low->high
-        [x_d0, r4, r3, r2, r1, out_conv(32)])."""
+        [x_d0, r4, r3, r2, r1, out_conv(32)]).  ``vit_feats``: the four encoder outputs of these B images when the caller has already
+        run :meth:`vit` on a larger batch (all tiles of an image in one launch per layer: fewer, better-filled GEMM launches)."""
         dt, dev = self.dtype, self.device
         B = img.shape[0]
         th, tw, C = self.th, self.tw, self.C
-        feats = self.vit(ops, img, taps)
+        feats = self.vit(ops, img, taps) if vit_feats is None else vit_feats
         if taps is not None:
             for i, f in enumerate(feats):
                 taps[f"vit_out{i}"] = f

@@ -68,6 +68,17 @@ def _ld(t):
     return ld
 
 
+def _fused_enabled():
+    """PF_WINO_FUSED (read per call): 1 (default) = eligible F(4x4,3x3) layers take the fused kernel, 0 = the three-step path"""
+    import os
+    return os.environ.get("PF_WINO_FUSED", "1") != "0"
+
+
+def _fused_group():
+    import os
+    return int(os.environ.get("PF_WINO_GS", "8"))
+
+
 class HipOps:
     name = "hip"
 
@@ -113,6 +124,18 @@ class HipOps:
         if _timed is not None and not wino:
             ms = C.c_float(0)
             check(_L.pf_conv_timed(C.byref(p), int(_timed), C.byref(ms), _stream()), "pf_conv_timed")
+            return ms.value
+        if wino and pw.wino_up is not None and _fused_enabled() and _L.pf_conv_winograd_fused_supported(C.byref(p)):
+            # fused F(4x4,3x3): one kernel, no V / M workspaces (csrc/wino_fused.hip)
+            assert y4.dtype == torch.float32 and (res is None or res.dtype == torch.float32) and (res2 is None or res2.dtype == torch.float32)
+            _p(pw.wino_up)
+            nnb, gs = pw.wino_up.shape[0], _fused_group()
+            if _timed is None:
+                check(_L.pf_conv_winograd_fused(C.byref(p), _p(pw.wino_up), nnb, gs, _stream()), "pf_conv_winograd_fused")
+                return y
+            ms = C.c_float(0)
+            check(_L.pf_conv_winograd_fused_timed(C.byref(p), _p(pw.wino_up), nnb, gs, int(_timed), C.byref(ms), _stream()),
+                  "pf_conv_winograd_fused_timed")
             return ms.value
         if wino:
             # float32 3x3 layers with enough pixels: input transform -> (m+2)^2 GEMMs -> output transform (csrc/winograd.hip)

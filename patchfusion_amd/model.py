@@ -158,6 +158,9 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
         self._side_stream = None
         self._aux_streams = []
         self.n_streams = int(_os.environ.get("PF_STREAMS", config.get("n_streams", 2)))
+        # ViT encoder of the fine branch over ALL tiles of this rank in one launch per layer (M = tiles x 1037 token rows) instead of
+        # once per process_num batch; the DPT head / fusion keep the process_num batches.  Identical numbers (no op mixes rows).
+        self.vit_batch_all = bool(config.get("vit_batch_all", True)) and _os.environ.get("PF_VIT_BATCH_ALL", "1") != "0"
         self._engine = None
         self._coarse_state = None
         if config.load_branch:
@@ -384,16 +387,27 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
             streams += self._aux_streams[:self.n_streams - 1]
             for a in streams[1:]:
                 a.wait_stream(main)
+        crops_all = vit_all = None
+        if self.vit_batch_all and (hi - lo) > process_num and hasattr(nets["fine"], "vit"):
+            crops_all = ops.empty((hi - lo, 3, ph, pw), torch.float32, dev)
+            ops.crop_resize(img, bt[lo:hi], crops_all)
+            vit_all = nets["fine"].vit(ops, crops_all)          # 4 x [tiles, th, tw, D]; runs while coarse + G2L use the side stream
+            for a in streams[1:]:
+                a.wait_stream(main)
         for bi, s in enumerate(range(lo, hi, process_num)):
             e = min(s + process_num, hi)
             stream = streams[bi % len(streams)]
             ctx = torch.cuda.stream(stream) if img.is_cuda else _nullcontext()
             with ctx:
-                crops = ops.empty((e - s, 3, ph, pw), torch.float32, dev)
-                ops.crop_resize(img, bt[s:e], crops)
-                # the fine branch does not depend on the coarse pass: it runs while the coarse branch + G2L
-                # (batch 1, low occupancy) execute on the side stream
-                fdepth, ffeats = nets["fine"].forward(ops, crops)
+                if crops_all is not None:
+                    crops = crops_all[s - lo:e - lo]
+                    fdepth, ffeats = nets["fine"].forward(ops, crops, vit_feats=[f[s - lo:e - lo] for f in vit_all])
+                else:
+                    crops = ops.empty((e - s, 3, ph, pw), torch.float32, dev)
+                    ops.crop_resize(img, bt[s:e], crops)
+                    # the fine branch does not depend on the coarse pass: it runs while the coarse branch + G2L
+                    # (batch 1, low occupancy) execute on the side stream
+                    fdepth, ffeats = nets["fine"].forward(ops, crops)
                 if coarse_ready is not None:
                     stream.wait_event(coarse_ready)
                 st = self._coarse_state

@@ -33,11 +33,14 @@ class PackedConv:
     korder: int = 0                 # K order of `w`: 0 = (ky, kx, c) tap-major; 1 = (c / 32, ky, kx, c % 32) chunk-major
     wino_m: int = 0                 # Winograd F(m x m, 3 x 3) output tile (2 | 4), 0 = direct kernel only
     wino_u: Optional[torch.Tensor] = None   # [(m+2)^2, rows, Kpad1] float32: G g G^T, each plane packed like a 1x1 weight
+    wino_up: Optional[torch.Tensor] = None  # m = 4 only: the same filters in the fragment order of the fused kernel (winograd_filters_fused)
 
     def to(self, device):
         self.w = self.w.to(device)
         if self.wino_u is not None:
             self.wino_u = self.wino_u.to(device)
+        if self.wino_up is not None:
+            self.wino_up = self.wino_up.to(device)
         if self.bias is not None:
             self.bias = self.bias.to(device)
         if self.scale is not None:
@@ -104,6 +107,25 @@ def winograd_filters(wk, m):
     return out.contiguous()
 
 
+def winograd_filters_fused(wk):
+    """Filters of the fused F(4x4,3x3) kernel (csrc/wino_fused.hip): wk [rows, 3, 3, cin_total] float32 (buffer channel layout,
+    cin_total % 8 == 0) -> [nnb, nkc, 36, 2, 64, 4] float32 in MFMA FRAGMENT order: for the 64-channel block nb, the 8-channel chunk
+    kc, the transform point `plane` and the channel half, lane (r = lane & 15, g = lane >> 4) holds
+        (U[n0 + 0 + r][c0], U[n0 + 0 + r][c0 + 1], U[n0 + 16 + r][c0], U[n0 + 16 + r][c0 + 1]),   n0 = 64 nb + 32 half, c0 = 8 kc + 2 g
+    i.e. the A operands of the two k-steps of v_mfma_f32_16x16x4_f32 for the wave's two 16-channel groups: one contiguous 1 KiB per
+    wave-load.  U = G g G^T in float64, rounded once; channels beyond `rows` are zero."""
+    G = torch.tensor(WINO_G[4], dtype=torch.float64)
+    rows, _, _, cin = wk.shape
+    assert cin % 8 == 0
+    nnb, nkc = (rows + 63) // 64, cin // 8
+    U = torch.einsum("ia,raxc,jx->ijrc", G, wk.double(), G).reshape(36, rows, cin).float()
+    Up = torch.zeros(36, nnb * 64, cin, dtype=torch.float32)
+    Up[:, :rows] = U
+    # dims: plane, nb, half, cg, r, kc, g, ks  ->  nb, kc, plane, half, g, r, cg, ks   (lane = 16 g + r, element = 2 cg + ks)
+    Up = Up.view(36, nnb, 2, 2, 16, nkc, 4, 2).permute(1, 5, 0, 2, 6, 4, 3, 7).contiguous()
+    return Up.view(nnb, nkc, 36, 2, 64, 4)
+
+
 def pack_conv(weight, bias=None, *, dtype, cin_map=None, cin_total=None, scale=None, bn=None, bn_eps=1e-5):
     """weight [Cout, Cin, KH, KW] (or [Cout, Cin] for nn.Linear).  ``cin_map``: list of
     (src_start, length, dst_start) placing original input channels into the buffer's channel axis;
@@ -149,7 +171,8 @@ def pack_conv(weight, bias=None, *, dtype, cin_map=None, cin_total=None, scale=N
         sp[:cout] = scale.detach().float().cpu()
     wm = winograd_mode() if (scale is None and winograd_eligible(cout_store, cin_total, KH, KW, dtype)) else 0
     wu = winograd_filters(wk, wm) if wm else None
-    return PackedConv(wp.to(dtype).contiguous(), bp, sp, KH, KW, cin_total, cout_store, cout, korder=korder, wino_m=wm, wino_u=wu)
+    wup = winograd_filters_fused(wk) if wm == 4 else None
+    return PackedConv(wp.to(dtype).contiguous(), bp, sp, KH, KW, cin_total, cout_store, cout, korder=korder, wino_m=wm, wino_u=wu, wino_up=wup)
 
 
 def pack_conv_transpose(weight, bias, *, dtype):

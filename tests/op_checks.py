@@ -104,6 +104,54 @@ def conv_winograd(dt):
     return max(errs), 8e-6, "winograd F(2,3) / F(4,3) vs direct f32"
 
 
+def conv_winograd_fused(dt):
+    """fused float32 Winograd F(4x4,3x3) (csrc/wino_fused.hip: LDS-DMA halo -> in-kernel B^T d B -> 36-plane MFMA -> in-kernel A^T M A +
+    epilogue) against the DIRECT float32 convolution, and against the three-step path it replaces.  Cases: partial tiles in both
+    directions, strips that wrap tile rows and images, W at the 29-pixel limit, Cout % 64 == 32 (idle upper channel half), several channel
+    blocks, channel-slice views of x / y / res2, relu_in, residuals, and two group sizes of the block order."""
+    import os
+    keys = ("PF_WINOGRAD", "PF_WINOGRAD_MIN_PIXELS", "PF_WINO_FUSED", "PF_WINO_GS")
+    old = {k: os.environ.get(k) for k in keys}
+    errs, errs3 = [], []
+    try:
+        os.environ["PF_WINOGRAD_MIN_PIXELS"] = "0"
+        os.environ["PF_WINOGRAD"] = "4"
+        for i, (B, H, W, cin, cout, gs, kw) in enumerate((
+                (2, 37, 41, 128, 160, 8, dict(act="relu")),
+                (1, 64, 64, 256, 128, 3, dict(relu_in=True, res=True, res2=True)),
+                (1, 30, 43, 544, 544, 8, dict()),
+                (3, 5, 29, 128, 96, 1, dict(act="relu", res=True)),
+                (8, 56, 74, 768, 256, 8, dict(act="relu")),
+                (1, 392, 518, 128, 32, 8, dict(act="relu")),
+                (2, 112, 148, 256, 256, 5, dict(relu_in=True, act="relu", res=True)))):
+            os.environ["PF_WINO_GS"] = str(gs)
+            g = torch.Generator().manual_seed(100 + i)
+            w = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+            pw = pk.pack_conv(w, torch.randn(cout, generator=g), dtype=torch.float32).to(DEV)
+            assert pw.wino_m == 4 and pw.wino_up is not None
+            xb = _rand((B, H, W, cin + 16), torch.float32, 200 + i)
+            x = xb[..., 8:8 + cin]
+            r1 = _rand((B, H, W, cout), torch.float32, 300 + i) if kw.get("res") else None
+            r2 = _rand((B, H, W, cout + 8), torch.float32, 400 + i)[..., :cout] if kw.get("res2") else None
+            outs = []
+            for o, direct, fused in ((hip(), None, "1"), (hip(), None, "0"), (ref_ops, True, "0")):
+                os.environ["PF_WINO_FUSED"] = fused
+                yb = torch.zeros((B, H, W, cout + 16), dtype=torch.float32, device=DEV)
+                o.conv(x, pw, yb[..., 8:8 + cout], pad=1, act=kw.get("act"), relu_in=kw.get("relu_in", False), res=r1, res2=r2, _direct=direct)
+                outs.append(yb)
+            errs.append(_err(outs[0], outs[2]))
+            errs3.append(_err(outs[0], outs[1]))
+            assert float(outs[0][..., :8].abs().max()) == 0.0 and float(outs[0][..., 8 + cout:].abs().max()) == 0.0
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    torch.cuda.synchronize()
+    return max(max(errs), max(errs3)), 3.2e-5, f"fused winograd F(4,3) vs direct f32 (max {max(errs):.2e}) and vs three-step (max {max(errs3):.2e})"
+
+
 def conv_gemm_qkv(dt):
     return _conv_case(dt, 1, 1, 2 * 1037, 384, 1152, 1)
 
@@ -512,7 +560,7 @@ CHECKS = {
     "conv_gemm_vitl_linear_shape": conv_gemm_vitl_linear_shape, "conv_dominant_launch": conv_dominant_launch,
     "conv_transpose": conv_transpose, "patch_embed_tokens": patch_embed_tokens, "layernorm": layernorm,
     "vit_attention": vit_attention, "swin_ops": swin_ops, "resize_ops": resize_ops, "roi_ops": roi_ops,
-    "conv_winograd": conv_winograd, "misc_ops": misc_ops, "bins_ops": bins_ops, "stitch_ops": stitch_ops,
+    "conv_winograd": conv_winograd, "conv_winograd_fused": conv_winograd_fused, "misc_ops": misc_ops, "bins_ops": bins_ops, "stitch_ops": stitch_ops,
 }
-F32_ONLY = {"bins_ops", "stitch_ops", "conv_winograd"}
+F32_ONLY = {"bins_ops", "stitch_ops", "conv_winograd", "conv_winograd_fused"}
 DTYPES = {"fp32": torch.float32, "bf16": torch.bfloat16}

@@ -90,6 +90,55 @@ def test_three_step_path_equals_direct_convolution(wino_env, m, shape):
     assert float((y - ref).abs().max() / ref.abs().max()) <= (1.5e-5 if m == 4 else 3e-6)
 
 
+@pytest.mark.parametrize("case", [
+    (1, 9, 37, 16, 48, True, False, False),       # two strips, channel half 1 has one valid 16-channel group
+    (2, 13, 41, 16, 32, False, True, True),       # strips wrap tile rows AND images; upper channel half idle; relu_in + residual
+    (1, 6, 150, 8, 96, True, False, False),       # two channel blocks, one long tile row
+    (1, 5, 29, 24, 64, False, False, True),       # W at the limit (8 tiles per row): five row segments in one strip
+])
+def test_fused_kernel_index_model_equals_direct_convolution(case):
+    """csrc/wino_fused.hip replayed lane by lane in numpy (tests/wino_fused_model.py: same constants and per-lane expressions for the
+    column table, the DMA slots, the transform lanes, the V image, the MFMA fragments against packing.winograd_filters_fused, the
+    accumulator layout and the epilogue exchange) must reproduce F.conv2d -- the part of the kernel that can be checked without a GPU."""
+    from tests import wino_fused_model as wm
+    B, H, W, cin, cout, relu, relu_in, with_res = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, H, W, cin, generator=g, dtype=torch.float64)
+    w = torch.randn(cout, cin, 3, 3, generator=g, dtype=torch.float64) / (9 * cin) ** 0.5
+    bias = torch.randn(cout, generator=g, dtype=torch.float64)
+    res = torch.randn(B, H, W, cout, generator=g, dtype=torch.float64) if with_res else None
+    rows = pk.round_up(pk.round_up(cout, 4), 16)
+    wk = torch.zeros(rows, 3, 3, cin)
+    wk[:cout] = w.float().permute(0, 2, 3, 1)
+    up = pk.winograd_filters_fused(wk)
+    assert tuple(up.shape) == ((cout + 63) // 64, cin // 8, 36, 2, 64, 4)
+    bp = np.zeros(rows)
+    bp[:cout] = bias.numpy()
+    y = wm.run(x.numpy(), up.numpy(), bp, relu, relu_in, res.numpy() if with_res else None, None, cout, gs=2)
+    xin = x.clamp(min=0) if relu_in else x
+    ref = F.conv2d(xin.permute(0, 3, 1, 2), w, bias, padding=1).permute(0, 2, 3, 1)
+    if relu:
+        ref = ref.clamp(min=0)
+    if with_res:
+        ref = ref + res
+    assert not np.isnan(y).any()                                     # every output written exactly by some (strip, channel block)
+    assert float(np.abs(y - ref.numpy()).max()) < 2e-5               # float32 rounding of the packed filters only
+
+
+def test_fused_filters_are_the_three_step_filters_in_fragment_order(wino_env):
+    wino_env(4)
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(96, 128, 3, 3, generator=g)
+    pw = pk.pack_conv(w, None, dtype=torch.float32)
+    assert pw.wino_up is not None and tuple(pw.wino_up.shape) == (2, 16, 36, 2, 64, 4)
+    U = pw.wino_u                                                     # [36, rows, Kpad]
+    for nb, kc, plane, half, lane, e in ((0, 0, 0, 0, 0, 0), (1, 15, 35, 0, 63, 3), (0, 7, 17, 1, 37, 2), (1, 3, 5, 0, 21, 1)):
+        r, gq, cg, ks = lane & 15, lane >> 4, e >> 1, e & 1
+        n, c = 64 * nb + 32 * half + 16 * cg + r, 8 * kc + 2 * gq + ks
+        want = float(U[plane, n, c]) if n < U.shape[1] else 0.0
+        assert float(pw.wino_up[nb, kc, plane, half, lane, e]) == want
+
+
 @pytest.mark.parametrize("m", [2, 4])
 def test_engine_end_to_end_through_the_winograd_path(wino_env, m, golden_dir):
     """the whole tiny pass with every eligible 3x3 layer (fusion U-Net, 256 channels) on the emulated three-step path: same

@@ -43,7 +43,11 @@ class BinsHead:
         self.seed_bounded, self.attr_bounded = kind in ("normed", "hybrid1"), kind in ("normed", "hybrid2")
         self.lo = float(bcfg.get("min_depth", 1e-3) if min_depth is None else min_depth)
         self.hi = float(bcfg.get("max_depth", 10) if max_depth is None else max_depth)
-        self.attr_type, self.attr_kind = bcfg.get("attractor_type", "inv"), bcfg.get("attractor_kind", "mean")
+        # defaults of ZoeDepth.build for a branch head (zoedepth_v1.py:41: attractor_type 'exp', attractor_kind 'sum'); the fusion head
+        # reads both straight from the config and fails without them (patchfusion.py:162)
+        if not with_rel and not ("attractor_type" in bcfg and "attractor_kind" in bcfg):
+            raise AttributeError("coarse_branch config needs attractor_type and attractor_kind for the fusion head (patchfusion.py:162)")
+        self.attr_type, self.attr_kind = bcfg.get("attractor_type", "exp"), bcfg.get("attractor_kind", "sum")
         if self.attr_kind not in ("mean", "sum"):
             raise KeyError(self.attr_kind)                          # attractor.py:118 indexes a dict with it
         self.n_attr = list(bcfg["n_attractors"])

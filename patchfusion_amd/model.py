@@ -172,7 +172,13 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
         """``self.<branch>.load_state_dict(sd, strict=True)`` of the reference: missing / unexpected keys raise."""
         want = [k[len(prefix):] for k in self.spec if k.startswith(prefix)]
         missing = [k for k in want if k not in branch_sd]
-        unexpected = [k for k in branch_sd if k not in set(want)]
+        wanted = set(want)
+        # type 'ZoeDepth': the MiDaS/BEiT core is external (engine.ExternalCoreBranchNet, injected provider); a real branch checkpoint
+        # still carries its weights under `core.` -- they belong to the provider, not to this module's parameter tree
+        external_core = getattr(self.config[prefix[:-1]], "type", None) == 'ZoeDepth'
+        unexpected = [k for k in branch_sd if k not in wanted and not (external_core and k.startswith("core."))]
+        if external_core:
+            branch_sd = {k: v for k, v in branch_sd.items() if k in wanted}
         if missing or unexpected:
             raise RuntimeError(f"Error(s) in loading state_dict for {prefix[:-1]}: Missing key(s): {missing[:8]}"
                                f"{' ...' if len(missing) > 8 else ''}; Unexpected key(s): {unexpected[:8]}"
@@ -256,7 +262,11 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
         """-> (coarse_prediction [1,1,h,w] f32, six coarse feature maps NCHW f32) like patchfusion.py:189-206"""
         st = self._coarse(image_lr)
         feats = [self.ops.nhwc_to_nchw(f) for f in st["feats"]]
-        st["handed_out"] = tuple(int(f.data_ptr()) for f in feats) + (int(st["depth"].data_ptr()),)
+        # the tensors handed to the caller are kept alive and remembered by IDENTITY and version counter: `infer_forward(tile_temp=...)`
+        # reuses the engine's own state only for exactly these objects, unmodified (an address comparison would also match foreign
+        # tensors that landed on recycled addresses, or the same tensors after an in-place write)
+        st["handed_out"] = tuple(feats) + (st["depth"],)
+        st["handed_out_versions"] = tuple(t._version for t in st["handed_out"])
         return st["depth"], feats
 
     def fine_forward(self, image_hr_crop):
@@ -271,14 +281,17 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
         tensors are re-laid out (a permute -- no arithmetic) and the patch-invariant G2L stacks are recomputed from them."""
         st = self._coarse_state
         feats = tile_temp['coarse_features']
-        key = tuple(int(f.data_ptr()) for f in feats) + (int(tile_temp['coarse_prediction'].data_ptr()),)
-        if st is not None and st.get("handed_out") == key:
+        given = tuple(feats) + (tile_temp['coarse_prediction'],)
+        mine = st.get("handed_out") if st is not None else None
+        if (mine is not None and len(mine) == len(given) and all(a is b for a, b in zip(mine, given))
+                and tuple(t._version for t in given) == st["handed_out_versions"]):
             return st
         nets = self._ensure_engine()
         dev, dt = self._device, self.compute_dtype
         nhwc = [f.detach().to(dev).permute(0, 2, 3, 1).contiguous().to(dt) for f in feats]
         depth = tile_temp['coarse_prediction'].detach().to(device=dev, dtype=torch.float32).contiguous()
-        st = dict(depth=depth, feats=nhwc, g2l=nets["g2l"].forward(self.ops, nhwc), handed_out=key)
+        st = dict(depth=depth, feats=nhwc, g2l=nets["g2l"].forward(self.ops, nhwc), handed_out=given,
+                  handed_out_versions=tuple(t._version for t in given))
         self._coarse_state = st
         return st
 

@@ -21,3 +21,18 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_collection_modifyitems(config, items):
+    """gpu-marked tests are skipped (not failed) on a box without a GPU, so a plain `pytest tests` works in the build container"""
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        return
+    skip = pytest.mark.skip(reason="needs a GPU (pytest -m gpu on the MI355X box)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)

@@ -284,3 +284,78 @@ def test_baseline_pretrain_train_mode_and_external_core_on_the_engine():
     d, _ = m(mode="infer", image_lr=lr.cuda(), image_hr=img.cuda(), cai_mode="m1", process_num=2)
     o = pf_oracle.BaselineOracle(bc, ps, raw, split, sd, "fine", core_provider=core).infer(lr, img, "m1", 2)
     assert d.shape == o.shape and float((d.cpu() - o).abs().max()) < 2e-4
+
+
+def test_configs3_geometry_8x8_tiles_vs_oracle_on_gpu():
+    """BASELINE.json configs[3] geometry through the HIP kernels: 2160x3840 split 8x8 = 64 tiles whose 270x480 raw crops are
+    UP-sampled to 392x518 by crop_resize_planar_kernel, stitched into a 3136x4144 map (DA-vits weights keep the oracle side short).
+    Engine: all 64 tiles.  Oracle (torch on this GPU): the coarse pass and six tiles spread over the grid incl. the corners."""
+    cfg, sd, m, img = build("vits", (392, 518), (2160, 3840), (8, 8), "fp32")
+    img = img.cuda()
+    lr = m.resizer(img)
+    d, _ = m(mode="infer", image_lr=lr, image_hr=img, cai_mode="m1", process_num=8)
+    assert tuple(d.shape) == (1, 1, 8 * 392, 8 * 518)
+    sdg = {k: v.cuda() for k, v in sd.items()}
+    orc = pf_oracle.Oracle(cfg, sdg)
+    tiles = (0, 7, 27, 36, 56, 63)
+    with torch.no_grad():
+        olr = orc.resizer(img)
+        assert float((olr - lr).abs().max()) < 1e-5
+        orc.coarse_depth, orc.coarse_feats = pf_oracle.branch_forward(sdg, "coarse_branch.", olr, cfg["coarse_branch"])
+        orc.g2l = pf_oracle.g2l_all(sdg, orc.coarse_feats)
+        tile_cfg = pf_oracle.prepare_tile_cfg(orc.ps, cfg["image_raw_shape"], cfg["patch_split_num"])
+        hr, wr = tile_cfg["patch_raw_shape"]
+        assert (hr, wr) == (270, 480)
+        crops, boxes = [], []
+        for t in tiles:
+            h, w = (t // 8) * hr, (t % 8) * wr
+            crops.append(orc.resizer(img[:, :, h:h + hr, w:w + wr])[0])
+            boxes.append([w, h, w + wr, h + hr])
+        ref = orc._predict(torch.stack(crops), torch.tensor(boxes, device="cuda").int(), tile_cfg, 3)[:, 0]
+    got = torch.stack([d[0, 0, (t // 8) * 392:(t // 8 + 1) * 392, (t % 8) * 518:(t % 8 + 1) * 518] for t in tiles])
+    err = float((got - ref).abs().max())
+    print(f"MEASURED 8x8 geometry (configs[3]), 6 of 64 tiles vs oracle: max {err:.3e}")
+    assert err <= 2e-4, err
+    del m, orc, sdg
+    torch.cuda.empty_cache()
+
+
+def test_rccl_world_size_one_gather_and_image_token_on_device():
+    """The only data-path collective (dist.all_gather_shards) and the same-image guard (one all_reduce) executed on DEVICE tensors
+    through RCCL (backend 'nccl'), world_size 1 -- the multi-rank logic is covered by the 2-rank gloo tests (tests/test_dist_cpu.py);
+    this one proves the RCCL path initialises and runs on this software stack.  Own process: a process group must not leak into
+    the other tests."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import os, sys, random, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from patchfusion_amd.config import make_config
+from patchfusion_amd.model import PatchFusion
+from patchfusion_amd.spec import patchfusion_spec, synthetic_state_dict
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29653', world_size=1, rank=0, device_id=torch.device('cuda', 0))
+cfg = make_config('vits', (112, 154), (448, 616), (2, 2))
+sd = synthetic_state_dict(patchfusion_spec(cfg), 0)
+img = torch.rand(1, 3, 448, 616, generator=torch.Generator().manual_seed(1234)).cuda()
+outs = []
+for shard in (False, True):
+    m = PatchFusion(cfg, compute_dtype='fp32', shard_patches=shard).eval()
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    random.seed(5621)
+    d, _ = m(mode='infer', image_lr=m.resizer(img), image_hr=img, cai_mode='r4', process_num=2)
+    outs.append(d.clone())
+same = m._same_image_token(m.resizer(img), img)
+assert bool(same)
+from patchfusion_amd.dist import all_gather_shards
+p = torch.randn(5, 7, 9, device='cuda')
+assert torch.equal(all_gather_shards(p, 5, 1), p)
+assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+dist.destroy_process_group()
+print('rccl-ok')
+""" % root
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "rccl-ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])

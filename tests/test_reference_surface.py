@@ -205,6 +205,34 @@ def test_infer_forward_with_the_reference_call_protocol(tiny):
             assert float((preds[3, 0] - br).abs().max()) < 1e-5
 
 
+def test_tile_temp_reuse_needs_identity_and_unmodified_tensors(tiny):
+    """The engine state of the last coarse_forward is reused only for the very tensor OBJECTS it handed out, unmodified: an in-place
+    write into them (new coarse data in the same storage) or foreign tensors -- which may sit on recycled addresses -- must rebuild
+    the state from tile_temp instead of silently using the stale one (round-2 advisor finding)."""
+    cfg, sd, m, img = tiny
+    lr = m.resizer(img)
+    with torch.no_grad():
+        cp, cf = m.coarse_forward(lr)
+        st0 = m._coarse_state
+        tt = dict(coarse_prediction=cp, coarse_features=cf)
+        assert m._state_from_tile_temp(tt) is st0                                  # untouched hand-out -> reuse
+        other = m.resizer(torch.rand(1, 3, *img.shape[2:], generator=torch.Generator().manual_seed(77)))
+        cp2, cf2 = m.coarse_forward(other)
+        want = [f.clone() for f in cf2]
+        for a, b in zip(cf, cf2):                                                   # caller refills the FIRST hand-out in place
+            a.copy_(b)
+        cp.copy_(cp2)
+        m._coarse_state = st0                                                       # ... and the engine still holds the old state
+        st = m._state_from_tile_temp(tt)
+        assert st is not st0
+        from patchfusion_amd.model import PatchFusion  # noqa: F401
+        nchw = [f.float().permute(0, 3, 1, 2) for f in st["feats"]]
+        assert all(float((a - b).abs().max()) < 1e-6 for a, b in zip(nchw, want))  # rebuilt from the NEW data
+        # foreign tensors with equal values: rebuilt as well (never matched by address)
+        st3 = m._state_from_tile_temp(dict(coarse_prediction=cp.clone(), coarse_features=[f.clone() for f in cf]))
+        assert st3 is not st
+
+
 @needs_ref
 @pytest.mark.reference
 def test_tile_geometry_equals_the_reference_method_over_many_shapes():

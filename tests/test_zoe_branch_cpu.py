@@ -99,3 +99,36 @@ def test_zoe_baseline_pretrain_matches_oracle_with_injected_core(target, mode):
         b = BaselinePretrain(bc, bc, None, 1e-3, 80, RAW, PS, SPLIT, target=target, ops=fake_ops)
         b.load_dict({k[len(target) + 8:]: v for k, v in sd.items()})
         b(mode="infer", image_lr=lr, image_hr=img)
+
+
+def test_zoe_branch_checkpoint_with_core_weights_loads_through_the_configdict_route(tmp_path):
+    """A real ZoeDepth branch checkpoint carries the MiDaS/BEiT weights under `core.` (they are the external provider's, not this
+    module's): the strict per-branch load of the mmengine ConfigDict route (patchfusion.py:105-109) must accept them -- and still
+    reject genuinely unknown / missing keys (round-2 advisor finding: BASELINE configs[4] could not be constructed via tools/test.py)."""
+    cfg = make_zoe_config(PS, RAW, SPLIT)
+    sd = synthetic_state_dict(patchfusion_spec(cfg), 0)
+    paths = []
+    for br in ("coarse_branch.", "fine_branch."):
+        bsd = {k[len(br):]: v for k, v in sd.items() if k.startswith(br)}
+        bsd["core.core.pretrained.model.blocks.0.attn.qkv.weight"] = torch.zeros(3, 3)     # the external core's own tensors
+        bsd["core.core.scratch.refinenet1.out_conv.bias"] = torch.zeros(4)
+        path = str(tmp_path / (br + "pth"))
+        torch.save({"model_state_dict": bsd}, path)
+        paths.append(path)
+
+    class ConfigDict(dict):          # stands in for mmengine.ConfigDict (model._is_mmengine_configdict checks the class name)
+        def to_dict(self):
+            return dict(self)
+
+    c = ConfigDict(cfg)
+    c["pretrain_model"] = paths
+    m = PatchFusion(c, ops=fake_ops, core_providers=(StandInCore(11), StandInCore(12)))
+    assert m.config.load_branch is True
+    got = m.state_dict()
+    assert all(torch.equal(got[k], v) for k, v in sd.items() if k.startswith(("coarse_branch.", "fine_branch.")))
+    # an unknown non-core key is still an error, like load_state_dict(strict=True)
+    bad = torch.load(paths[0])
+    bad["model_state_dict"]["conv2.bogus"] = torch.zeros(1)
+    torch.save(bad, paths[0])
+    with pytest.raises(RuntimeError, match="Unexpected"):
+        PatchFusion(c, ops=fake_ops, core_providers=(StandInCore(11), StandInCore(12)))

@@ -76,8 +76,9 @@ int pf_conv_winograd(const pf_conv_params* p, int m, const void* U, int u_rows, 
 
 /* FUSED Winograd F(4x4, 3x3) (csrc/wino_fused.hip): the same layers in ONE kernel -- the transformed input and the transform-domain
  * products never exist in HBM.  `p` as for pf_conv_winograd (p->w is not read); `up` = the filters in MFMA fragment order
- * [nnb][Cin/8][36][2][64][4] floats (patchfusion_amd/packing.py winograd_filters_fused), nnb = ceil(Cout/64); `gs` = strips of 32
- * output tiles per block group (L2 locality knob, >= 1).  Needs Cin % 8 == 0, Cout % 4 == 0, W >= 29, B*H*W*x_ld < 2^31:
+ * [nnb][Cin/8][36][2][64][4] floats (patchfusion_amd/packing.py winograd_filters_fused), nnb = ceil(Cout/64); `gs` & 0xffff =
+ * super-tiles (32 output tiles: 4 x 8 or 8 x 4, picked for the least padding) per block group (L2 locality knob, >= 1), `gs` >> 16 = 0
+ * or a forced super-tile width 8 | 4 (tuning aid).  Needs Cin % 16 == 0, Cin >= 32, Cout % 4 == 0, B*H*W*x_ld < 2^31:
  * pf_conv_winograd_fused_supported(p) returns 1 when `p` qualifies, else 0 (callers then take pf_conv_winograd / pf_conv). */
 int pf_conv_winograd_fused_supported(const pf_conv_params* p);
 int pf_conv_winograd_fused(const pf_conv_params* p, const void* up, int nnb, int gs, void* stream);

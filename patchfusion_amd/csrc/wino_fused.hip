@@ -5,48 +5,48 @@
 //
 //   Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A
 //
-// Work decomposition.  A block owns a STRIP of 32 consecutive 4x4 output tiles (flattened (b, ty, tx) order, so only the 4-pixel tile
-// rounding of W is padding) x 64 output channels x ALL 36 transform points; it walks Cin in chunks of 8 channels:
-//   raw   : the strip's 6-row input halo of one chunk, brought by LDS-DMA (global_load_lds_dwordx4) into a 2-deep ring,
-//           layout [row a 0..5][channel quad h 0..1][column x 0..137][4 ch]  (16-byte slots = the DMA granule)
-//   V     : B^T d B of that chunk, [36 planes][32 tiles][8 ch] float, 2-deep; written by the four "transform" waves from raw
+// Work decomposition.  A block owns a SUPER-TILE of 32 output tiles of 4x4 pixels (4 x 8 or 8 x 4 tiles, picked per layer for the
+// least padding) x 64 output channels x ALL 36 transform points; it walks Cin in chunks of 8 channels:
+//   raw   : the super-tile's input halo (18 x 34 or 34 x 18 pixels) of SIXTEEN channels = two chunks, brought by LDS-DMA
+//           (global_load_lds_dwordx4) into a 2-deep ring; pixel-major, 64 contiguous bytes per pixel, so that a 128-byte line of x is
+//           touched twice per 32 channels.  (Round-3 measurement of the first version, which fetched 8 channels = 2 x 16 B per
+//           pixel and chunk: the L1 fill of 1792 partial lines per chunk bounded the kernel at 0.52 of the MFMA peak whatever the
+//           MFMA work -- 544->32 and 544->544 took the same time per chunk.)  The 16-byte slots of a pixel PAIR are XOR-swizzled
+//           with the tile column (source side, like igemm.hip) so that the transform's 4-byte reads are bank-conflict free.
+//   V     : B^T d B of one chunk, [36 planes][32 tiles][8 ch] float, 2-deep; written by the four "transform" waves from raw
 //   MFMA  : wave (pg, half) multiplies planes 9 pg .. 9 pg + 8 for output channels n0 + 32 half .. + 31:
 //           D[n][tile] += U_plane[n][c] V_plane[tile][c] on v_mfma_f32_16x16x4_f32 (A = filters, B = tiles), 144 accumulator
 //           registers per lane; the filter fragments come straight from global memory (L2) into registers in a pre-packed
 //           fragment order (packing.winograd_filters_fused) -- no other wave needs them, so staging them in LDS would buy nothing --
-//           as a rolling prefetch: plane p's registers are reloaded for the NEXT chunk right after its last MFMA of this chunk.
+//           as a rolling prefetch: plane p's registers are reloaded for a later plane / the next chunk right after its last MFMA.
 //   out   : after the last chunk the 36 planes of a (tile, 4-channel) unit sit in four different waves; they are exchanged through
 //           LDS once (one channel half at a time: 36 x 32 x 32 floats = 144 KiB), A^T M A + bias / ReLU / residual(s) run in registers
 //           and y is stored once.
-// Per 8-channel chunk a block issues 576 MFMAs (4608 cycles per SIMD) against 26 KiB of input halo and 72 KiB of filter fragments.
+// Per 8-channel chunk a block issues 576 MFMAs (4608 cycles per SIMD) against 19 KiB of input halo and 72 KiB of filter fragments.
 //
 // Wave roles (8 waves, two per SIMD: wave w and w+4).  Waves 0-3 ("transform", channel half 0): planes 0-3, the input transform of
-// the next chunk (VALU + LDS only), planes 4-8.  Waves 4-7 ("DMA", channel half 1): the 28 LDS-DMA pieces of the chunk after next
-// first, then planes 0-8.  The two waves of a SIMD are therefore never both outside their MFMA stream.
+// the next chunk (VALU + LDS only), planes 4-8.  Waves 4-7 ("DMA", channel half 1): 5 LDS-DMA pieces each (half a raw stage per
+// chunk) first, then planes 0-8.  The two waves of a SIMD are therefore never both outside their MFMA stream.
 // One barrier per chunk.  Global loads and the DMA are issued from inline asm and counted by hand (s_waitcnt vmcnt(N) naming the
 // registers it releases, like the hand-counted LDS reads of igemm.hip); tools/asm_vm_audit.py replays the in-order VMEM queue over the
-// emitted assembly (tests/test_kernel_resources.py).
+// emitted assembly (tests/test_kernel_resources.py).  tests/wino_fused_model.py replays every index formula below lane by lane.
 #include <atomic>
 #include "pf_common.h"
 #include "../../include/pf_hip.h"
 
 namespace {
 
-constexpr int NT = 32;                        // tiles per strip
-constexpr int RC = 138;                       // raw columns per (row, quad) plane: 4*32 + 2*5 segments; RC*4 % 32 == 8 (bank spread of h)
-constexpr int RAW_SLOTS = 6 * 2 * RC;         // 1656 16-byte slots
-constexpr int DMA_PIECES = 28;                // 1 KiB each, 7 per DMA wave
-constexpr int RAW_STAGE = DMA_PIECES * 1024;  // 28672
+constexpr int NT = 32;                        // tiles per super-tile
+constexpr int DMA_PIECES = 40;                // 1 KiB each per 16-channel raw stage: 10 per DMA wave, 5 per chunk
+constexpr int RAW_STAGE = DMA_PIECES * 1024;  // 40960 >= 18*34 pixels x 64 B
 constexpr int V_STAGE = 36 * NT * 8 * 4;      // 36864
-constexpr int LDS_V0 = 2 * RAW_STAGE;         // 57344
-constexpr int LDS_MAIN = LDS_V0 + 2 * V_STAGE;   // 131072
+constexpr int LDS_V0 = 2 * RAW_STAGE;         // 81920
+constexpr int LDS_MAIN = LDS_V0 + 2 * V_STAGE;   // 155648
 constexpr int LDS_EPI = 36 * NT * 8 * 16;     // 147456: [36][32 tiles][8 quads] float4 = one channel half of M
-constexpr int LDS_TAB = LDS_EPI;              // column table behind everything: colbase[144], colty[144]
-constexpr int LDS_TOTAL = LDS_TAB + 2 * 144 * 4;
+constexpr int LDS_TOTAL = LDS_MAIN;
 constexpr int U_PLANE = 2 * 1024;             // bytes between planes of the packed filters (2 halves x 64 lanes x 16 B)
 constexpr int U_CHUNK = 36 * U_PLANE;         // bytes between 8-channel chunks
-static_assert(LDS_MAIN <= LDS_EPI && LDS_TOTAL <= 160 * 1024, "LDS budget");
-static_assert((RC * 4) % 32 == 8 && RAW_SLOTS <= DMA_PIECES * 64, "raw layout");
+static_assert(LDS_EPI <= LDS_MAIN && LDS_TOTAL <= 160 * 1024, "LDS budget");
 
 struct WF {
   const float* x; int x_ld; int B, H, W, Cin;
@@ -54,7 +54,7 @@ struct WF {
   float* y; int y_ld; int Cout;
   const float* bias; int relu; int relu_in;
   const float* res; int res_ld; const float* res2; int res2_ld;
-  int TH, TW, T, nstrips, nnb, nkc, gs;
+  int TH, TW, nsy, nsx, nsuper, nnb, nkc, gs;
 };
 
 __device__ __attribute__((aligned(256))) unsigned int wf_zero_page[64];
@@ -113,21 +113,29 @@ __device__ __forceinline__ void at6(const float (&m)[6], float (&o)[4]) {
   o[3] = d12 + 8.f * d34 + m[5];
 }
 
-// input transform of one (tile, channel) unit: 36 LDS reads at raw + (a*2*RC + b)*16, B^T d B, 36 LDS writes at vout + k*1024
-__device__ __forceinline__ void transform_unit(const char* raw, char* vout, float lo) {
+// pixel-pair swizzle mask of a raw pixel whose column lies in tile column sx (= rx >> 2): the 8 slots of 16 bytes of a pixel pair
+// hold slot (xp << 2 | quad) ^ mask.  For the four tile columns of a 32-lane group and both channel quads of a chunk the transform's
+// reads then hit 8 distinct slots = 32 distinct banks.
+__device__ __forceinline__ int swz(int sx) { return ((sx & 1) << 2) | (sx & 2); }
+
+// input transform of one (tile, channel) unit: 36 LDS reads at raw + (col[b] ^ jx) + a*ROWB, B^T d B, 36 LDS writes at vout + k*1024
+template <int ROWB>
+__device__ __forceinline__ void transform_unit(const char* raw, const int (&col)[6], int jx, char* vout, float lo) {
   float d[6][6];
 #pragma unroll
-  for (int a = 0; a < 6; ++a)
+  for (int b = 0; b < 6; ++b) {
+    const char* cp = raw + (col[b] ^ jx);
 #pragma unroll
-    for (int b = 0; b < 6; ++b) d[a][b] = fmaxf(*reinterpret_cast<const float*>(raw + (a * 2 * RC + b) * 16), lo);
+    for (int a = 0; a < 6; ++a) d[a][b] = fmaxf(*reinterpret_cast<const float*>(cp + a * ROWB), lo);
+  }
 #pragma unroll
   for (int b = 0; b < 6; ++b) {                     // B^T d : down the columns
-    float col[6];
+    float c6[6];
 #pragma unroll
-    for (int a = 0; a < 6; ++a) col[a] = d[a][b];
-    bt6(col);
+    for (int a = 0; a < 6; ++a) c6[a] = d[a][b];
+    bt6(c6);
 #pragma unroll
-    for (int a = 0; a < 6; ++a) d[a][b] = col[a];
+    for (int a = 0; a < 6; ++a) d[a][b] = c6[a];
   }
 #pragma unroll
   for (int i = 0; i < 6; ++i) {                     // (B^T d) B : along the rows
@@ -137,6 +145,7 @@ __device__ __forceinline__ void transform_unit(const char* raw, char* vout, floa
   }
 }
 
+template <int SW>     // super-tile width in tiles: 8 -> 4 x 8 tiles (18 x 34 halo), 4 -> 8 x 4 tiles (34 x 18 halo)
 __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -144,75 +153,70 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
   const int pg = wave & 3, half = wave >> 2;
   const unsigned smem_base = lds_addr(smem);
 
-  // ---- block -> (strip, channel block): groups of `gs` strips x all channel blocks, strips fastest (consecutive ids share an XCD:
-  // its ~32 resident blocks are gs strips x a few channel blocks whose filter streams overlap in L2, and the strips' input halos are
-  // re-read by the other channel blocks of the group while they are still L2 / MALL resident) ----
-  int strip, nb;
+  constexpr int SH = NT / SW, RR = 4 * SH + 2, RCc = 4 * SW + 2, RP = RCc / 2, ROWB = RP * 128, RAW_USED = RR * RCc * 4;
+  static_assert(RAW_USED <= DMA_PIECES * 64, "raw stage");
+  // ---- block -> (super-tile, channel block): groups of `gs` super-tiles x all channel blocks, super-tiles fastest (consecutive ids
+  // share an XCD: its ~32 resident blocks are gs super-tiles x a few channel blocks whose filter streams overlap in L2, and the
+  // input halos are re-read by the other channel blocks of the group while they are still L2 / MALL resident) ----
+  int sidx, nb;
   {
     const int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     const int per_group = p.gs * p.nnb;
     const int group = bid / per_group;
     const int first = group * p.gs;
-    const int gsz = min(p.nstrips - first, p.gs);
+    const int gsz = min(p.nsuper - first, p.gs);
     const int in_g = bid - group * per_group;
     nb = in_g / gsz;
-    strip = first + (in_g - nb * gsz);
+    sidx = first + (in_g - nb * gsz);
   }
-  const int T0 = strip * NT;
-  const int THW = p.TH * p.TW;
-  const int tx0 = T0 % p.TW;
+  const int b_img = sidx / (p.nsy * p.nsx);
+  const int srem = sidx - b_img * (p.nsy * p.nsx);
+  const int sty = srem / p.nsx, stx = srem - sty * p.nsx;
   const int n0 = nb * 64;
   const bool active = n0 + half * 32 < p.Cout;          // (wave-uniform) this wave's 32 output channels exist
 
-  // ---- column table: raw column x -> (pixel index of (b, row 0, ix) or -1, tile row ty).  Tile slot s of the strip owns raw columns
-  // 4 s + 2 g(s) .. + 5, g(s) = number of tile-row wraps before slot s; neighbours of one tile row share two columns ----
-  int* colbase = reinterpret_cast<int*>(smem + LDS_TAB);
-  int* colty = colbase + 144;
-  if (tid < 144) { colbase[tid] = -1; colty[tid] = 0; }
-  __syncthreads();
-  if (tid < NT && T0 + tid < p.T) {
-    const int t = T0 + tid;
-    const int b = t / THW, rem = t - b * THW;
-    const int ty = rem / p.TW, tx = rem - ty * p.TW;
-    const int c0 = 4 * tid + 2 * ((tx0 + tid) / p.TW);
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const int ix = 4 * tx - 1 + j;
-      colbase[c0 + j] = (ix >= 0 && ix < p.W) ? b * p.H * p.W + ix : -1;
-      colty[c0 + j] = ty;
-    }
-  }
-  __syncthreads();
-
-  // ---- DMA lanes (waves 4-7): piece 7 pg + i, slot = piece*64 + lane -> (a, h, x); element offset of the 4 channels or -1 ----
-  int doff[7];
+  // ---- DMA lanes (waves 4-7): pieces hf*20 + 5 pg + i (hf = half of the raw stage issued in this chunk interval); physical slot =
+  // piece*64 + lane -> pixel pair, swizzled (pixel parity, channel quad); element offset of the 4 channels or -1 ----
+  int doff[10];
   if (half) {
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      const int slot = (7 * pg + i) * 64 + lane;
+    for (int i = 0; i < 10; ++i) {
+      const int slot = ((i / 5) * 20 + 5 * pg + (i % 5)) * 64 + lane;
       doff[i] = -1;
-      if (slot < RAW_SLOTS) {
-        const int a = slot / (2 * RC), rem = slot - a * (2 * RC);
-        const int h = rem / RC, xc = rem - h * RC;
-        const int cb = colbase[xc], iy = 4 * colty[xc] - 1 + a;
-        if (cb >= 0 && iy >= 0 && iy < p.H) doff[i] = (cb + iy * p.W) * p.x_ld + 4 * h;
+      if (slot < RAW_USED) {
+        const int pairidx = slot >> 3, sp = slot & 7;
+        const int ry = pairidx / RP, pr = pairidx - ry * RP;
+        const int sg = sp ^ swz(pr >> 1);
+        const int rx = 2 * pr + (sg >> 2), q = sg & 3;
+        const int iy = 4 * SH * sty - 1 + ry, ix = 4 * SW * stx - 1 + rx;
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) doff[i] = ((b_img * p.H + iy) * p.W + ix) * p.x_ld + 4 * q;
       }
     }
   }
   const char* zero = reinterpret_cast<const char*>(wf_zero_page);
   const float* __restrict__ xg = p.x;
-  auto dma = [&](int chunk, int stage) {
-    const unsigned dst = smem_base + stage * RAW_STAGE + (7 * pg) * 1024;
+  // half `hf` (0 | 1) of the raw stage of channel group G (16 channels = chunks 2G, 2G+1) -> stage G & 1
+  auto dma_half = [&](int G, int hf) {
+    const unsigned dst = smem_base + (G & 1) * RAW_STAGE + (hf * 20 + 5 * pg) * 1024;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      const char* src = doff[i] >= 0 ? reinterpret_cast<const char*>(xg + (long)doff[i] + chunk * 8) : zero;
+    for (int i = 0; i < 5; ++i) {
+      const int o = hf ? doff[5 + i] : doff[i];
+      const char* src = o >= 0 ? reinterpret_cast<const char*>(xg + (long)o + G * 16) : zero;
       glds16(src, dst + i * 1024);
     }
   };
 
-  // ---- transform lanes (waves 0-3): unit = (tile slot 8 pg + lane/8, channel lane%8) ----
+  // ---- transform lanes (waves 0-3): unit = (tile slot 8 pg + lane/8, channel lane%8 of the chunk); col[b] = byte offset of raw
+  // pixel (4 sy, 4 sx + b), channel quad h of an EVEN chunk (odd chunks: ^ 32), + 4 cc ----
   const int tc = lane & 7, tsl = 8 * pg + (lane >> 3);
-  const int t_rd = ((((tc >> 2) * RC + 4 * tsl + 2 * ((tx0 + tsl) / p.TW)) * 4) + (tc & 3)) * 4;
+  int tcol[6];
+  {
+    const int sy = tsl / SW, sx = tsl % SW, h = tc >> 2, cc = tc & 3;
+    const int m0 = swz(sx), m1 = swz(sx + 1);
+#pragma unroll
+    for (int b = 0; b < 6; ++b)
+      tcol[b] = ((((4 * sy * RP + 2 * sx + (b >> 1)) * 8) + ((((b & 1) << 2) | h) ^ (b < 4 ? m0 : m1))) * 16) + cc * 4;
+  }
   const int t_wr = (64 * pg + lane) * 4;
   const float lo = p.relu_in ? 0.f : -INFINITY;
 
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
     const int q = ((pg & 1) * 4 + g4) ^ (r & 7);
     const int n = n0 + half * 32 + (pg & 1) * 16 + 4 * g4;
     const char* mp = smem + (tl * 8 + q) * 16;
-    float tcol[4][6][4];
+    float tq[4][6][4];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       f32x4 m[6];
@@ -294,14 +298,12 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
         float o[4];
         at6(col, o);
 #pragma unroll
-        for (int po = 0; po < 4; ++po) tcol[po][j][e] = o[po];
+        for (int po = 0; po < 4; ++po) tq[po][j][e] = o[po];
       }
       __builtin_amdgcn_sched_barrier(0);      // keep hipcc from hoisting all 36 reads (144 registers) above the first column
     }
-    const int tile = T0 + tl;
-    if (tile >= p.T || n >= p.Cout) return;
-    const int b = tile / THW, rem = tile - b * THW;
-    const int ty = rem / p.TW, tx = rem - ty * p.TW;
+    const int ty = SH * sty + tl / SW, tx = SW * stx + tl % SW, b = b_img;
+    if (ty >= p.TH || tx >= p.TW || n >= p.Cout) return;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n);
     const float be[4] = {bv.x, bv.y, bv.z, bv.w};
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
       float o[4][4];                                   // [channel e][column qo]
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float row[6] = {tcol[po][0][e], tcol[po][1][e], tcol[po][2][e], tcol[po][3][e], tcol[po][4][e], tcol[po][5][e]};
+        const float row[6] = {tq[po][0][e], tq[po][1][e], tq[po][2][e], tq[po][3][e], tq[po][4][e], tq[po][5][e]};
         at6(row, o[e]);
       }
       if (oy >= p.H) continue;
@@ -346,8 +348,8 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
     gload16(u[1], ubase + U_PLANE);
     gload16(u[2], ubase + 2 * U_PLANE);
     vm_wait<0>(u[0]); vm_wait<0>(u[1]); vm_wait<0>(u[2]);
-    lds_barrier<1>();                                         // raw chunks 0, 1 have landed (the DMA waves waited for them)
-    transform_unit(smem + t_rd, smem + LDS_V0 + t_wr, lo);
+    lds_barrier<1>();                                         // raw group 0 has landed (the DMA waves waited for it)
+    transform_unit<ROWB>(smem, tcol, 0, smem + LDS_V0 + t_wr, lo);        // chunk 0: group 0, even
     lds_barrier<1>();
     for (int c = 0; c < nkc - 1; ++c) {
       const char* vcur = smem + LDS_V0 + (c & 1) * V_STAGE + b_rd;
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
       WF_PLANE(1, 1, 2, gload16(u[1], uc + 4 * U_PLANE))
       WF_PLANE(2, 2, 2, gload16(u[2], uc + 5 * U_PLANE))
       WF_PLANE(3, 0, 2, gload16(u[0], uc + 6 * U_PLANE))
-      transform_unit(smem + ((c + 1) & 1) * RAW_STAGE + t_rd, smem + LDS_V0 + ((c + 1) & 1) * V_STAGE + t_wr, lo);
+      transform_unit<ROWB>(smem + (((c + 1) >> 1) & 1) * RAW_STAGE, tcol, ((c + 1) & 1) << 5, smem + LDS_V0 + ((c + 1) & 1) * V_STAGE + t_wr, lo);
       WF_PLANE(4, 1, 2, gload16(u[1], uc + 7 * U_PLANE))
       WF_PLANE(5, 2, 2, gload16(u[2], uc + 8 * U_PLANE))
       WF_PLANE(6, 0, 2, gload16(u[0], uc + U_CHUNK))
@@ -387,10 +389,12 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
     lds_barrier<1>();
   } else {
     // ================= DMA waves: all nine fragments of a chunk stay in registers; plane P's is re-requested for the next chunk right
-    // after its last MFMA.  VMEM queue when plane P waits: [u_c(P), u_c(P+1..8), DMA(c) x 7, u_{c+1}(0..P-1)] -> 15 younger
+    // after its last MFMA.  VMEM queue when plane P waits: [u_c(P), u_c(P+1..8), DMA(c) x 5, u_{c+1}(0..P-1)] -> 13 younger
     // (DMA(c-1) was issued before u_c(P)) =================
-    dma(0, 0);
-    dma(1, 1);
+    const int ng = nkc >> 1;
+    dma_half(0, 0);
+    dma_half(0, 1);
+    dma_half(min(1, ng - 1), 0);          // first half of group 1 (the 'interval -1' share)
     if (active) {
 #pragma unroll
       for (int i = 0; i < 9; ++i) gload16(u[i], ubase + i * U_PLANE);
@@ -403,24 +407,24 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
       for (int c = 0; c < nkc - 1; ++c) {
         const char* vcur = smem + LDS_V0 + (c & 1) * V_STAGE + b_rd;
         const char* un = ubase + (long)(c + 1) * U_CHUNK;
-        dma(min(c + 2, nkc - 1), c & 1);   // raw chunk c+2 -> the stage chunk c was transformed from (a harmless re-load at the end)
+        dma_half(min((c + 3) >> 1, ng - 1), (c + 1) & 1);   // group (c+3)/2: first half in odd c, second half in even c (a harmless re-load at the end)
         WF_BLOAD(0, be0, be1)
-        WF_PLANE(0, 0, 15, gload16(u[0], un))
-        WF_PLANE(1, 1, 15, gload16(u[1], un + 1 * U_PLANE))
-        WF_PLANE(2, 2, 15, gload16(u[2], un + 2 * U_PLANE))
-        WF_PLANE(3, 3, 15, gload16(u[3], un + 3 * U_PLANE))
-        WF_PLANE(4, 4, 15, gload16(u[4], un + 4 * U_PLANE))
-        WF_PLANE(5, 5, 15, gload16(u[5], un + 5 * U_PLANE))
-        WF_PLANE(6, 6, 15, gload16(u[6], un + 6 * U_PLANE))
-        WF_PLANE(7, 7, 15, gload16(u[7], un + 7 * U_PLANE))
-        WF_PLANE(8, 8, 15, gload16(u[8], un + 8 * U_PLANE))
+        WF_PLANE(0, 0, 13, gload16(u[0], un))
+        WF_PLANE(1, 1, 13, gload16(u[1], un + 1 * U_PLANE))
+        WF_PLANE(2, 2, 13, gload16(u[2], un + 2 * U_PLANE))
+        WF_PLANE(3, 3, 13, gload16(u[3], un + 3 * U_PLANE))
+        WF_PLANE(4, 4, 13, gload16(u[4], un + 4 * U_PLANE))
+        WF_PLANE(5, 5, 13, gload16(u[5], un + 5 * U_PLANE))
+        WF_PLANE(6, 6, 13, gload16(u[6], un + 6 * U_PLANE))
+        WF_PLANE(7, 7, 13, gload16(u[7], un + 7 * U_PLANE))
+        WF_PLANE(8, 8, 13, gload16(u[8], un + 8 * U_PLANE))
         vm_wait_plain<9>();                // DMA(c) has landed: only the nine reloads are younger
         lds_barrier<2>();
       }
     } else {
       // the upper channel half does not exist (last channel block of a layer with Cout % 64 == 32): this wave only feeds the DMA
       for (int c = 0; c < nkc - 1; ++c) {
-        dma(min(c + 2, nkc - 1), c & 1);
+        dma_half(min((c + 3) >> 1, ng - 1), (c + 1) & 1);
         vm_wait_plain<0>();
         lds_barrier<2>();
       }
@@ -449,9 +453,22 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
 #undef WF_NONE
 }
 
-std::atomic<unsigned long long> g_attr_done{0};
+template <int SW>
+int launch_sw(const WF& a, hipStream_t st) {
+  static std::atomic<unsigned long long> attr_done{0};
+  int dev = 0;
+  hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<SW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    attr_done.fetch_or(bit, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(wino_fused_kernel<SW>, dim3((unsigned)((long)a.nsuper * a.nnb)), dim3(512), LDS_TOTAL, st, a);
+  return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_LAUNCH;
+}
 
-int launch(const pf_conv_params* p, const void* up, int nnb, int gs, hipStream_t st) {
+// `shape`: 0 = pick the super-tile shape with fewer blocks (less padding), 8 = 4 x 8 tiles, 4 = 8 x 4 tiles
+int launch(const pf_conv_params* p, const void* up, int nnb, int gs, int shape, hipStream_t st) {
   WF a;
   a.x = static_cast<const float*>(p->x); a.x_ld = p->x_ld; a.B = p->B; a.H = p->H; a.W = p->W; a.Cin = p->Cin;
   a.up = static_cast<const float*>(up);
@@ -460,40 +477,34 @@ int launch(const pf_conv_params* p, const void* up, int nnb, int gs, hipStream_t
   a.res = static_cast<const float*>(p->res); a.res_ld = p->res_ld;
   a.res2 = static_cast<const float*>(p->res2); a.res2_ld = p->res2_ld;
   a.TH = (p->H + 3) / 4; a.TW = (p->W + 3) / 4;
-  const long T = (long)p->B * a.TH * a.TW;
-  a.T = (int)T;
-  a.nstrips = (int)((T + NT - 1) / NT);
+  const long n8 = (long)((a.TH + 3) / 4) * ((a.TW + 7) / 8), n4 = (long)((a.TH + 7) / 8) * ((a.TW + 3) / 4);
+  const int sw = shape == 8 || shape == 4 ? shape : (n4 < n8 ? 4 : 8);
+  const int sh = NT / sw;
+  a.nsy = (a.TH + sh - 1) / sh; a.nsx = (a.TW + sw - 1) / sw;
+  a.nsuper = p->B * a.nsy * a.nsx;
   a.nnb = nnb;
   a.nkc = p->Cin / 8;
   a.gs = gs < 1 ? 1 : gs;
-  int dev = 0;
-  hipGetDevice(&dev);
-  const unsigned long long bit = 1ull << (dev & 63);
-  if (!(g_attr_done.load(std::memory_order_acquire) & bit)) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
-    g_attr_done.fetch_or(bit, std::memory_order_release);
-  }
-  hipLaunchKernelGGL(wino_fused_kernel, dim3((unsigned)((long)a.nstrips * nnb)), dim3(512), LDS_TOTAL, st, a);
-  return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_LAUNCH;
+  return sw == 8 ? launch_sw<8>(a, st) : launch_sw<4>(a, st);
 }
 
 }  // namespace
 
 extern "C" int pf_conv_winograd_fused_supported(const pf_conv_params* p) {
   if (!p || p->dtype != PF_DTYPE_F32 || p->KH != 3 || p->KW != 3 || p->stride != 1 || p->pad != 1 || p->shuffle > 1 || p->scale) return 0;
-  if (p->OH != p->H || p->OW != p->W || p->Cin % 8 || p->Cin < 16 || p->Cout % 4 || p->Cout <= 0) return 0;
+  if (p->OH != p->H || p->OW != p->W || p->Cin % 16 || p->Cin < 32 || p->Cout % 4 || p->Cout <= 0) return 0;
   if (p->act != PF_ACT_NONE && p->act != PF_ACT_RELU) return 0;
-  if (p->W < 29) return 0;                                               // at least 8 tiles per tile row (<= 5 row segments per strip)
   if (p->x_ld % 4 || p->y_ld % 4 || (p->res && p->res_ld % 4) || (p->res2 && p->res2_ld % 4)) return 0;
   const long pix = (long)p->B * p->H * p->W;
-  if (pix * p->x_ld >= (1L << 31) || (long)p->B * ((p->H + 3) / 4) * ((p->W + 3) / 4) >= (1L << 31)) return 0;
+  if (pix * p->x_ld >= (1L << 31) || (long)p->B * ((p->H + 15) / 16) * ((p->W + 15) / 16) * ((p->Cout + 63) / 64) >= (1L << 31)) return 0;
   return 1;
 }
 
 extern "C" int pf_conv_winograd_fused(const pf_conv_params* p, const void* up, int nnb, int gs, void* stream) {
   if (!p || !up || !p->x || !p->y) return PF_ERR_ARG;
   if (!pf_conv_winograd_fused_supported(p) || nnb != (p->Cout + 63) / 64) return PF_ERR_ARG;
-  return launch(p, up, nnb, gs, reinterpret_cast<hipStream_t>(stream));
+  // gs: low 16 bits = super-tiles per block group; bits 16.. = forced super-tile shape (8 | 4, 0 = automatic) -- tuning aid
+  return launch(p, up, nnb, gs & 0xffff, gs >> 16, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int pf_conv_winograd_fused_timed(const pf_conv_params* p, const void* up, int nnb, int gs, int iters, float* ms, void* stream) {

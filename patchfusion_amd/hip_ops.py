@@ -75,8 +75,9 @@ def _fused_enabled():
 
 
 def _fused_group():
+    """PF_WINO_GS: super-tiles per block group (L2 locality knob); PF_WINO_SHAPE: 0 = automatic, 8 | 4 = forced super-tile width (tuning)"""
     import os
-    return int(os.environ.get("PF_WINO_GS", "8"))
+    return (int(os.environ.get("PF_WINO_GS", "8")) & 0xffff) | (int(os.environ.get("PF_WINO_SHAPE", "0")) << 16)
 
 
 class HipOps:

@@ -160,7 +160,9 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
         self.n_streams = int(_os.environ.get("PF_STREAMS", config.get("n_streams", 2)))
         # ViT encoder of the fine branch over ALL tiles of this rank in one launch per layer (M = tiles x 1037 token rows) instead of
         # once per process_num batch; the DPT head / fusion keep the process_num batches.  Identical numbers (no op mixes rows).
-        self.vit_batch_all = bool(config.get("vit_batch_all", True)) and _os.environ.get("PF_VIT_BATCH_ALL", "1") != "0"
+        # Off by default: measured 290.2 vs 287.0 ms per image (round 3, gpurun_out/r3a_bench_*.json) -- with two streams the tails of
+        # the 8-tile launches are already filled by the other batch.
+        self.vit_batch_all = bool(config.get("vit_batch_all", False)) or _os.environ.get("PF_VIT_BATCH_ALL", "0") == "1"
         self._engine = None
         self._coarse_state = None
         if config.load_branch:

@@ -90,15 +90,16 @@ def test_three_step_path_equals_direct_convolution(wino_env, m, shape):
     assert float((y - ref).abs().max() / ref.abs().max()) <= (1.5e-5 if m == 4 else 3e-6)
 
 
+@pytest.mark.parametrize("sw", [8, 4])
 @pytest.mark.parametrize("case", [
-    (1, 9, 37, 16, 48, True, False, False),       # two strips, channel half 1 has one valid 16-channel group
-    (2, 13, 41, 16, 32, False, True, True),       # strips wrap tile rows AND images; upper channel half idle; relu_in + residual
-    (1, 6, 150, 8, 96, True, False, False),       # two channel blocks, one long tile row
-    (1, 5, 29, 24, 64, False, False, True),       # W at the limit (8 tiles per row): five row segments in one strip
+    (1, 9, 37, 16, 48, True, False, False),       # several super-tiles, channel half 1 has one valid 16-channel group
+    (2, 13, 41, 16, 32, False, True, True),       # two images; upper channel half idle; relu_in + residual
+    (1, 6, 150, 16, 96, True, False, False),      # two channel blocks, one long tile row
+    (1, 37, 5, 32, 64, False, False, True),       # narrower than one super-tile: mostly padding tiles
 ])
-def test_fused_kernel_index_model_equals_direct_convolution(case):
+def test_fused_kernel_index_model_equals_direct_convolution(case, sw):
     """csrc/wino_fused.hip replayed lane by lane in numpy (tests/wino_fused_model.py: same constants and per-lane expressions for the
-    column table, the DMA slots, the transform lanes, the V image, the MFMA fragments against packing.winograd_filters_fused, the
+    super-tile order, the swizzled DMA slots, the transform lanes, the V image, the MFMA fragments against packing.winograd_filters_fused, the
     accumulator layout and the epilogue exchange) must reproduce F.conv2d -- the part of the kernel that can be checked without a GPU."""
     from tests import wino_fused_model as wm
     B, H, W, cin, cout, relu, relu_in, with_res = case
@@ -114,7 +115,9 @@ def test_fused_kernel_index_model_equals_direct_convolution(case):
     assert tuple(up.shape) == ((cout + 63) // 64, cin // 8, 36, 2, 64, 4)
     bp = np.zeros(rows)
     bp[:cout] = bias.numpy()
-    y = wm.run(x.numpy(), up.numpy(), bp, relu, relu_in, res.numpy() if with_res else None, None, cout, gs=2)
+    conflicts = []
+    y = wm.run(x.numpy(), up.numpy(), bp, relu, relu_in, res.numpy() if with_res else None, None, cout, gs=2, SW=sw, conflicts=conflicts)
+    assert max(conflicts) == 1                                       # the pixel-pair swizzle keeps the transform's LDS reads conflict free
     xin = x.clamp(min=0) if relu_in else x
     ref = F.conv2d(xin.permute(0, 3, 1, 2), w, bias, padding=1).permute(0, 2, 3, 1)
     if relu:

@@ -1,17 +1,17 @@
 """Lane-level numpy model of csrc/wino_fused.hip (test infrastructure).
 
 The fused Winograd kernel cannot be executed in the build container (no GPU), and almost everything that can go wrong in it is
-INDEX arithmetic: the strip / column table, the LDS-DMA slot mapping, the transform lanes, the V image, the MFMA fragment
-lanes against the pre-packed filter order (packing.winograd_filters_fused), the accumulator layout and the epilogue exchange.
-This model replays exactly those formulas -- same constants, same per-lane expressions, byte addresses into emulated LDS
-arrays, v_mfma_f32_16x16x4_f32 semantics on 64-lane operand vectors -- so that tests/test_winograd_cpu.py can check the
-mapping against F.conv2d before a GPU minute is spent.  It does not model timing, s_waitcnt or barriers.
+INDEX arithmetic: the super-tile / block order, the LDS-DMA slot mapping with its pixel-pair swizzle, the transform lanes, the V
+image, the MFMA fragment lanes against the pre-packed filter order (packing.winograd_filters_fused), the accumulator layout and
+the epilogue exchange.  This model replays exactly those formulas -- same constants, same per-lane expressions, byte addresses
+into emulated LDS arrays, v_mfma_f32_16x16x4_f32 semantics on 64-lane operand vectors -- so that tests/test_winograd_cpu.py can
+check the mapping against F.conv2d before a GPU minute is spent.  It does not model timing, s_waitcnt or barriers.
 """
 import numpy as np
 
-NT, RC = 32, 138
-RAW_SLOTS = 6 * 2 * RC
-RAW_STAGE = 28 * 1024
+NT = 32
+PIECES = 40                       # 1 KiB LDS-DMA pieces per 16-channel raw stage (10 per DMA wave, 5 per chunk interval)
+RAW_STAGE = PIECES * 1024
 V_STAGE = 36 * NT * 8 * 4
 U_PLANE, U_CHUNK = 2048, 36 * 2048
 
@@ -32,88 +32,105 @@ def mfma_16x16x4(a, b, c):
     return out
 
 
-def run(x, up, bias, relu, relu_in, res, res2, cout, gs=8):
-    """x [B,H,W,Cin] float64/32 NHWC; up = winograd_filters_fused(...) as numpy [nnb,nkc,36,2,64,4]; returns y [B,H,W,cout]."""
+def swz(sx):
+    """pixel-pair swizzle mask of a raw pixel whose column is in tile column sx (= rx >> 2)"""
+    return ((sx & 1) << 2) | (sx & 2)
+
+
+def run(x, up, bias, relu, relu_in, res, res2, cout, gs=8, SW=8, conflicts=None):
+    """x [B,H,W,Cin] NHWC; up = winograd_filters_fused(...) as numpy [nnb,nkc,36,2,64,4]; SW = super-tile width in tiles (8: 4x8 tiles,
+    4: 8x4); returns y [B,H,W,cout].  `conflicts`: optional list that receives the worst LDS bank multiplicity of the transform reads."""
     x = np.asarray(x, dtype=np.float64)
     B, H, W, Cin = x.shape
-    up_bytes = np.asarray(up, dtype=np.float64).reshape(-1)            # index in floats = byte offset / 4
+    up_f = np.asarray(up, dtype=np.float64).reshape(-1)            # index in floats = byte offset / 4
+    SH = 32 // SW
+    RR, RCc = 4 * SH + 2, 4 * SW + 2
+    RP = RCc // 2
+    ROWB = RP * 128
+    RAW_USED = RR * RCc * 4
+    assert RAW_USED <= PIECES * 64 and Cin % 16 == 0
     TH, TW = (H + 3) // 4, (W + 3) // 4
-    assert TW >= 8 and Cin % 8 == 0
-    T = B * TH * TW
-    nstrips, nnb, nkc = (T + NT - 1) // NT, (cout + 63) // 64, Cin // 8
+    NSY, NSX = (TH + SH - 1) // SH, (TW + SW - 1) // SW
+    nsuper, nnb, nkc = B * NSY * NSX, (cout + 63) // 64, Cin // 8
+    NG = nkc // 2
     y = np.full((B, H, W, cout), np.nan)
     xf = x.reshape(-1)
     x_ld = Cin
-    THW = TH * TW
     lane = np.arange(64)
-    nblocks = nstrips * nnb
+    nblocks = nsuper * nnb
     seen = set()
     for bid in range(nblocks):          # (the XCD remap is a bijection of block ids; the model walks logical ids)
         per_group = gs * nnb
         group = bid // per_group
         first = group * gs
-        gsz = min(nstrips - first, gs)
+        gsz = min(nsuper - first, gs)
         in_g = bid - group * per_group
         nb = in_g // gsz
-        strip = first + (in_g - nb * gsz)
-        assert (strip, nb) not in seen
-        seen.add((strip, nb))
-        T0 = strip * NT
-        tx0 = T0 % TW
+        sidx = first + (in_g - nb * gsz)
+        assert (sidx, nb) not in seen
+        seen.add((sidx, nb))
+        b_img = sidx // (NSY * NSX)
+        rem = sidx - b_img * NSY * NSX
+        sty, stx = rem // NSX, rem % NSX
         n0 = nb * 64
-        # ---- column table
-        colbase = np.full(144, -1, dtype=np.int64)
-        colty = np.zeros(144, dtype=np.int64)
-        for tid in range(NT):
-            if T0 + tid < T:
-                t = T0 + tid
-                b = t // THW
-                rem = t - b * THW
-                ty, tx = rem // TW, rem % TW
-                c0 = 4 * tid + 2 * ((tx0 + tid) // TW)
-                for j in range(6):
-                    ix = 4 * tx - 1 + j
-                    assert c0 + j < RC
-                    colbase[c0 + j] = b * H * W + ix if 0 <= ix < W else -1
-                    colty[c0 + j] = ty
-        # ---- DMA offsets per (wave pg, piece i, lane)
-        doff = np.full((4, 7, 64), -1, dtype=np.int64)
+        # ---- DMA offsets per (wave pg, i, lane): i < 5 first half of a stage, i >= 5 second half
+        doff = np.full((4, 10, 64), -1, dtype=np.int64)
+        dpiece = np.zeros((4, 10), dtype=np.int64)
         for pg in range(4):
-            for i in range(7):
+            for i in range(10):
+                piece = (i // 5) * 20 + 5 * pg + (i % 5)
+                dpiece[pg, i] = piece
                 for l in range(64):
-                    slot = (7 * pg + i) * 64 + l
-                    if slot < RAW_SLOTS:
-                        a = slot // (2 * RC)
-                        rem = slot - a * 2 * RC
-                        h, xc = rem // RC, rem % RC
-                        cb, iy = colbase[xc], 4 * colty[xc] - 1 + a
-                        if cb >= 0 and 0 <= iy < H:
-                            doff[pg, i, l] = (cb + iy * W) * x_ld + 4 * h
+                    slot = piece * 64 + l
+                    if slot < RAW_USED:
+                        pairidx, sp = slot >> 3, slot & 7
+                        ry, pr = pairidx // RP, pairidx % RP
+                        sg = sp ^ swz(pr >> 1)
+                        xp, q = sg >> 2, sg & 3
+                        rx = 2 * pr + xp
+                        iy, ix = 4 * SH * sty - 1 + ry, 4 * SW * stx - 1 + rx
+                        if 0 <= iy < H and 0 <= ix < W:
+                            doff[pg, i, l] = ((b_img * H + iy) * W + ix) * x_ld + 4 * q
+        assert sorted(dpiece.reshape(-1).tolist()) == list(range(40))
         acc = np.zeros((8, 9, 2, 2, 64, 4))      # [wave][plane][tg][cg][lane][e]
+        raw = None
         for kc in range(nkc):
-            raw = np.zeros(RAW_STAGE // 4)
-            for pg in range(4):
-                for i in range(7):
-                    dst = ((7 * pg + i) * 1024) // 4
-                    for l in range(64):
-                        o = doff[pg, i, l]
-                        raw[dst + 4 * l: dst + 4 * l + 4] = xf[o + kc * 8: o + kc * 8 + 4] if o >= 0 else 0.0
-            # ---- transform (waves 0-3)
+            G, j = kc >> 1, kc & 1
+            if j == 0:                            # a raw stage holds the 16 channels of chunks 2G and 2G+1
+                raw = np.full(RAW_STAGE // 4, np.nan)
+                for pg in range(4):
+                    for i in range(10):
+                        dst = (dpiece[pg, i] * 1024) // 4
+                        for l in range(64):
+                            o = doff[pg, i, l]
+                            raw[dst + 4 * l: dst + 4 * l + 4] = xf[o + 16 * G: o + 16 * G + 4] if o >= 0 else 0.0
+            # ---- transform (waves 0-3): unit = (tile slot 8 pg + lane/8, channel lane%8 of this chunk)
             V = np.zeros(V_STAGE // 4)
+            jx = j << 5
             for pg in range(4):
+                banks = {}
                 for l in range(64):
                     tc, tsl = l & 7, 8 * pg + (l >> 3)
-                    t_rd = ((((tc >> 2) * RC + 4 * tsl + 2 * ((tx0 + tsl) // TW)) * 4) + (tc & 3)) * 4
+                    sy, sx = tsl // SW, tsl % SW
+                    h, cc = tc >> 2, tc & 3
+                    m0, m1 = swz(sx), swz(sx + 1)
+                    col = [(((4 * sy * RP + 2 * sx + (b >> 1)) * 8) + ((((b & 1) << 2) | h) ^ (m0 if b < 4 else m1))) * 16 + cc * 4 for b in range(6)]
                     t_wr = (64 * pg + l) * 4
                     d = np.empty((6, 6))
                     for a in range(6):
                         for b in range(6):
-                            v = raw[(t_rd + (a * 2 * RC + b) * 16) // 4]
+                            adr = (col[b] ^ jx) + a * ROWB
+                            v = raw[adr // 4]
+                            assert not np.isnan(v), (pg, l, a, b)
                             d[a, b] = max(v, 0.0) if relu_in else v
+                            if conflicts is not None:
+                                banks.setdefault((a, b, l >> 5), []).append((adr // 4) % 32)
                     v = BT @ d @ BT.T
                     for i in range(6):
-                        for j in range(6):
-                            V[(t_wr + (i * 6 + j) * 1024) // 4] = v[i, j]
+                        for jj in range(6):
+                            V[(t_wr + (i * 6 + jj) * 1024) // 4] = v[i, jj]
+                if conflicts is not None:
+                    conflicts.append(max(max(np.bincount(np.array(bk), minlength=32)) for bk in banks.values()))
             # ---- MFMA (all waves)
             for wave in range(8):
                 pg, half = wave & 3, wave >> 2
@@ -124,7 +141,7 @@ def run(x, up, bias, relu, relu_in, res, res2, cout, gs=8):
                 ubase = ((((nb * nkc) * 36 + 9 * pg) * 2 + half) * 1024 + lane * 16) // 4
                 for P in range(9):
                     uo = ubase + (kc * U_CHUNK + P * U_PLANE) // 4
-                    u = np.stack([up_bytes[uo + e] for e in range(4)], axis=1)        # [64, 4]
+                    u = np.stack([up_f[uo + e] for e in range(4)], axis=1)        # [64, 4]
                     for tg in range(2):
                         bo = (b_rd + P * 1024 + tg * 512) // 4
                         bx, by = V[bo], V[bo + 1]
@@ -157,15 +174,12 @@ def run(x, up, bias, relu, relu_in, res, res2, cout, gs=8):
                     mp = (tl * 8 + q) * 16
                     m = np.empty((6, 6, 4))
                     for i in range(6):
-                        for j in range(6):
-                            o = (mp + (i * 6 + j) * (32 * 8 * 16)) // 4
-                            m[i, j] = M[o:o + 4]
-                    tile = T0 + tl
-                    if tile >= T or n >= cout:
+                        for jj in range(6):
+                            o = (mp + (i * 6 + jj) * (32 * 8 * 16)) // 4
+                            m[i, jj] = M[o:o + 4]
+                    ty, tx = SH * sty + tl // SW, SW * stx + tl % SW
+                    if ty >= TH or tx >= TW or n >= cout:
                         continue
-                    b = tile // THW
-                    rem = tile - b * THW
-                    ty, tx = rem // TW, rem % TW
                     out = np.einsum("pi,ije,qj->pqe", AT, m, AT)      # [4, 4, 4 channels]
                     for po in range(4):
                         oy = 4 * ty + po
@@ -181,10 +195,10 @@ def run(x, up, bias, relu, relu_in, res, res2, cout, gs=8):
                             if relu:
                                 v = np.maximum(v, 0.0)
                             if res is not None:
-                                v += res[b, oy, ox, n:n + 4]
+                                v += res[b_img, oy, ox, n:n + 4]
                             if res2 is not None:
-                                v += res2[b, oy, ox, n:n + 4]
-                            assert np.isnan(y[b, oy, ox, n]).all() if False else True
-                            y[b, oy, ox, n:n + 4] = v
+                                v += res2[b_img, oy, ox, n:n + 4]
+                            assert np.isnan(y[b_img, oy, ox, n:n + 4]).all()      # written exactly once
+                            y[b_img, oy, ox, n:n + 4] = v
     assert len(seen) == nblocks
     return y

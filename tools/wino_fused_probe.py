@@ -26,16 +26,17 @@ def check():
     os.environ["PF_WINOGRAD"] = "4"
     os.environ["PF_WINOGRAD_MIN_PIXELS"] = "0"
     cases = [
-        (1, 8, 32, 16, 32, 8, {}),                                   # one strip, one channel block, idle upper half
-        (1, 8, 32, 16, 64, 8, {}),
-        (1, 9, 37, 16, 48, 2, dict(act="relu")),
+        (1, 8, 32, 32, 32, 8, {}),                                   # one super-tile, one channel block, idle upper half
+        (1, 8, 32, 32, 64, 8, {}),
+        (1, 9, 37, 48, 48, 2, dict(act="relu")),
         (2, 13, 41, 32, 32, 2, dict(relu_in=True, res=True)),
-        (1, 6, 150, 8 * 4, 96, 8, dict(act="relu")),
+        (1, 6, 150, 32, 96, 8 | (4 << 16), dict(act="relu")),        # forced 8 x 4 super-tiles
         (3, 5, 29, 128, 96, 1, dict(act="relu", res=True)),
         (2, 37, 41, 128, 160, 8, dict(act="relu")),
         (1, 64, 64, 256, 128, 3, dict(relu_in=True, res=True, res2=True)),
         (1, 30, 43, 544, 544, 8, {}),
-        (8, 56, 74, 768, 256, 8, dict(act="relu")),
+        (8, 56, 74, 768, 256, 8 | (8 << 16), dict(act="relu")),       # forced 4 x 8 super-tiles
+        (1, 37, 5, 32, 64, 2, dict(res=True)),
         (2, 112, 148, 256, 256, 5, dict(relu_in=True, act="relu", res=True)),
         (1, 392, 518, 128, 32, 8, dict(act="relu")),
     ]
@@ -43,7 +44,7 @@ def check():
     for i, (B, H, W, cin, cout, gs, kw) in enumerate(cases):
         t0 = time.time()
         try:
-            os.environ["PF_WINO_GS"] = str(gs)
+            os.environ["PF_WINO_GS"], os.environ["PF_WINO_SHAPE"] = str(gs & 0xffff), str(gs >> 16)
             g = torch.Generator().manual_seed(100 + i)
             w = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
             pw = pk.pack_conv(w, torch.randn(cout, generator=g), dtype=torch.float32, cin_total=cin).to(DEV)
@@ -111,12 +112,12 @@ def timing(only):
         line = f"{name:14s} B{B} {H}x{W} {cin}->{cout}: three-step {ms3:8.3f} ms ({fl_d / ms3 / 1e9:6.1f} TF/s direct-eq) | fused"
         os.environ["PF_WINO_FUSED"] = "1"
         best = None
-        for gs in (1, 2, 4, 8, 16, 64):
-            os.environ["PF_WINO_GS"] = str(gs)
+        for gs, shp in ((1, 0), (4, 0), (8, 0), (16, 0), (64, 0), (8, 8), (8, 4)):
+            os.environ["PF_WINO_GS"], os.environ["PF_WINO_SHAPE"] = str(gs), str(shp)
             ms = ops.conv(x, pw, y, pad=1, act="relu", _timed=3)
-            line += f" gs{gs}: {ms:.3f}"
+            line += f" gs{gs}{'/sw' + str(shp) if shp else ''}: {ms:.3f}"
             if best is None or ms < best[0]:
-                best = (ms, gs)
+                best = (ms, f"{gs}/sw{shp}")
         line += (f" | best gs{best[1]} {best[0]:.3f} ms = {fl_w / best[0] / 1e9:6.1f} TF/s executed ({fl_w / best[0] / 1e9 / 157.3:.3f} of f32 peak), "
                  f"{fl_d / best[0] / 1e9:6.1f} TF/s direct-eq, {ms3 / best[0]:.2f}x three-step")
         print(line, flush=True)

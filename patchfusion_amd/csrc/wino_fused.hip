@@ -13,7 +13,8 @@
 //           pixel and chunk: the L1 fill of 1792 partial lines per chunk bounded the kernel at 0.52 of the MFMA peak whatever the
 //           MFMA work -- 544->32 and 544->544 took the same time per chunk.)  The 16-byte slots of a pixel PAIR are XOR-swizzled
 //           with the tile column (source side, like igemm.hip) so that the transform's 4-byte reads are bank-conflict free.
-//   V     : B^T d B of one chunk, [36 planes][32 tiles][8 ch] float, 2-deep; written by the four "transform" waves from raw
+//   V     : B^T d B of one chunk, 36 planes x (32 tiles x 8 ch) float in a bank-rotated order, 2-deep; written by the four
+//           "transform" waves from raw
 //   MFMA  : wave (pg, half) multiplies planes 9 pg .. 9 pg + 8 for output channels n0 + 32 half .. + 31:
 //           D[n][tile] += U_plane[n][c] V_plane[tile][c] on v_mfma_f32_16x16x4_f32 (A = filters, B = tiles), 144 accumulator
 //           registers per lane; the filter fragments come straight from global memory (L2) into registers in a pre-packed
@@ -55,7 +56,14 @@ struct WF {
   const float* bias; int relu; int relu_in;
   const float* res; int res_ld; const float* res2; int res2_ld;
   int TH, TW, nsy, nsx, nsuper, nnb, nkc, gs;
+  int dbg;   // only read by the PF_WF_DBG measurement build (make wfdbg; never part of libpf_hip.so; results are WRONG when non-zero):
+             // 1 = filter loads always hit chunk 0, 2 = no input transform, 4 = no DMA, 8 / 16 = no MFMA planes in the transform / DMA waves
 };
+#ifdef PF_WF_DBG
+#define WF_DBG(p, bit) ((p).dbg & (bit))
+#else
+#define WF_DBG(p, bit) 0
+#endif
 
 __device__ __attribute__((aligned(256))) unsigned int wf_zero_page[64];
 
@@ -96,13 +104,12 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __bui
 
 // B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]   (same formulas as winograd.hip)
 __device__ __forceinline__ void bt6(float (&d)[6]) {
-  const float o0 = 4.f * d[0] - 5.f * d[2] + d[4];
-  const float o1 = -4.f * (d[1] + d[2]) + d[3] + d[4];
-  const float o2 = 4.f * (d[1] - d[2]) - d[3] + d[4];
-  const float o3 = -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
-  const float o4 = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
-  const float o5 = 4.f * d[1] - 5.f * d[3] + d[5];
-  d[0] = o0; d[1] = o1; d[2] = o2; d[3] = o3; d[4] = o4; d[5] = o5;
+  // 12 operations: o1/o2 = (d4 - 4 d2) +- (d3 - 4 d1), o3/o4 = (d4 - d2) +- 2 (d3 - d1)
+  const float p = fmaf(-4.f, d[2], d[4]), q = fmaf(-4.f, d[1], d[3]);
+  const float r = d[4] - d[2], s = d[3] - d[1];
+  const float o0 = fmaf(4.f, d[0], fmaf(-5.f, d[2], d[4]));
+  const float o5 = fmaf(4.f, d[1], fmaf(-5.f, d[3], d[5]));
+  d[0] = o0; d[1] = p + q; d[2] = p - q; d[3] = fmaf(2.f, s, r); d[4] = fmaf(-2.f, s, r); d[5] = o5;
 }
 // A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
 __device__ __forceinline__ void at6(const float (&m)[6], float (&o)[4]) {
@@ -120,13 +127,19 @@ __device__ __forceinline__ int swz(int sx) { return ((sx & 1) << 2) | (sx & 2); 
 
 // input transform of one (tile, channel) unit: 36 LDS reads at raw + (col[b] ^ jx) + a*ROWB, B^T d B, 36 LDS writes at vout + k*1024
 template <int ROWB>
-__device__ __forceinline__ void transform_unit(const char* raw, const int (&col)[6], int jx, char* vout, float lo) {
+__device__ __forceinline__ void transform_unit(const char* raw, const int (&col)[6], int jx, char* vout, bool relu_in) {
   float d[6][6];
 #pragma unroll
   for (int b = 0; b < 6; ++b) {
     const char* cp = raw + (col[b] ^ jx);
 #pragma unroll
-    for (int a = 0; a < 6; ++a) d[a][b] = fmaxf(*reinterpret_cast<const float*>(cp + a * ROWB), lo);
+    for (int a = 0; a < 6; ++a) d[a][b] = *reinterpret_cast<const float*>(cp + a * ROWB);
+  }
+  if (relu_in) {                                    // (wave-uniform) ResidualConvUnit: ReLU on load
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = 0; b < 6; ++b) d[a][b] = fmaxf(d[a][b], 0.f);
   }
 #pragma unroll
   for (int b = 0; b < 6; ++b) {                     // B^T d : down the columns
@@ -217,12 +230,16 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
     for (int b = 0; b < 6; ++b)
       tcol[b] = ((((4 * sy * RP + 2 * sx + (b >> 1)) * 8) + ((((b & 1) << 2) | h) ^ (b < 4 ? m0 : m1))) * 16) + cc * 4;
   }
-  const int t_wr = (64 * pg + lane) * 4;
-  const float lo = p.relu_in ? 0.f : -INFINITY;
+  // V image of a plane (1 KiB): dword (c >> 1) * 64 + (tile >> 4) * 32 + (((tile & 15) + 4 (c >> 1)) & 15) * 2 + (c & 1).  The rotation by
+  // 4 (c >> 1) makes BOTH sides conflict free: the transform's 4-byte stores (32 lanes = 8 channels x 4 tiles -> 32 banks) and the
+  // MFMA waves' 8-byte fragment reads, which hipcc merges into ds_read2_b64 = 16-lane groups over 32 banks (16 tiles x 2 dwords).
+  // (Round-3 PMC of the first layout, 32 bytes per tile: 58 % of the LDS cycles were bank conflicts -- 4-way on every fragment read.)
+  const int t_wr = ((tc >> 1) * 64 + (tsl >> 4) * 32 + ((((tsl & 15) + 4 * (tc >> 1)) & 15) * 2) + (tc & 1)) * 4;
+  const bool lo = p.relu_in != 0;
 
   // ---- MFMA lanes: B fragment (tile r, channels 2 g4, 2 g4 + 1) of plane 9 pg + P, tile group tg ----
   const int r = lane & 15, g4 = lane >> 4;
-  const int b_rd = (r * 8 + 2 * g4) * 4 + 9 * pg * 1024;
+  const int b_rd = (g4 * 64 + ((r + 4 * g4) & 15) * 2) * 4 + 9 * pg * 1024;      // tile group tg: + 128 bytes
   const char* ubase = reinterpret_cast<const char*>(p.up) + ((((long)nb * p.nkc) * 36 + 9 * pg) * 2 + half) * 1024 + lane * 16;
 
   f32x4 acc[9][2][2];
@@ -241,7 +258,7 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
   // hit different accumulators: 40-cycle dependent latency against the 32-cycle issue), then reload u[S] from NEXT
 #define WF_BLOAD(P, B0, B1)                                                                              \
   B0 = *reinterpret_cast<const float2*>(vcur + (P) * 1024);                                              \
-  B1 = *reinterpret_cast<const float2*>(vcur + (P) * 1024 + 512);
+  B1 = *reinterpret_cast<const float2*>(vcur + (P) * 1024 + 128);
 #define WF_PLANE_(P, S, WAITN, NEXT, BC0, BC1, PREFETCH)                                                 \
   {                                                                                                      \
     PREFETCH                                                                                             \
@@ -353,18 +370,23 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
     lds_barrier<1>();
     for (int c = 0; c < nkc - 1; ++c) {
       const char* vcur = smem + LDS_V0 + (c & 1) * V_STAGE + b_rd;
-      const char* uc = ubase + (long)c * U_CHUNK;
-      WF_BLOAD(0, be0, be1)
-      WF_PLANE(0, 0, 2, gload16(u[0], uc + 3 * U_PLANE))
-      WF_PLANE(1, 1, 2, gload16(u[1], uc + 4 * U_PLANE))
-      WF_PLANE(2, 2, 2, gload16(u[2], uc + 5 * U_PLANE))
-      WF_PLANE(3, 0, 2, gload16(u[0], uc + 6 * U_PLANE))
-      transform_unit<ROWB>(smem + (((c + 1) >> 1) & 1) * RAW_STAGE, tcol, ((c + 1) & 1) << 5, smem + LDS_V0 + ((c + 1) & 1) * V_STAGE + t_wr, lo);
-      WF_PLANE(4, 1, 2, gload16(u[1], uc + 7 * U_PLANE))
-      WF_PLANE(5, 2, 2, gload16(u[2], uc + 8 * U_PLANE))
-      WF_PLANE(6, 0, 2, gload16(u[0], uc + U_CHUNK))
-      WF_PLANE(7, 1, 2, gload16(u[1], uc + U_CHUNK + U_PLANE))
-      WF_PLANE(8, 2, 2, gload16(u[2], uc + U_CHUNK + 2 * U_PLANE))
+      const char* uc = ubase + (long)(WF_DBG(p, 1) ? 0 : c) * U_CHUNK;
+      if (!WF_DBG(p, 8)) {
+        WF_BLOAD(0, be0, be1)
+        WF_PLANE(0, 0, 2, gload16(u[0], uc + 3 * U_PLANE))
+        WF_PLANE(1, 1, 2, gload16(u[1], uc + 4 * U_PLANE))
+        WF_PLANE(2, 2, 2, gload16(u[2], uc + 5 * U_PLANE))
+        WF_PLANE(3, 0, 2, gload16(u[0], uc + 6 * U_PLANE))
+      }
+      if (!WF_DBG(p, 2))
+        transform_unit<ROWB>(smem + (((c + 1) >> 1) & 1) * RAW_STAGE, tcol, ((c + 1) & 1) << 5, smem + LDS_V0 + ((c + 1) & 1) * V_STAGE + t_wr, lo);
+      if (!WF_DBG(p, 8)) {
+        WF_PLANE(4, 1, 2, gload16(u[1], uc + 7 * U_PLANE))
+        WF_PLANE(5, 2, 2, gload16(u[2], uc + 8 * U_PLANE))
+        WF_PLANE(6, 0, 2, gload16(u[0], uc + U_CHUNK))
+        WF_PLANE(7, 1, 2, gload16(u[1], uc + U_CHUNK + U_PLANE))
+        WF_PLANE(8, 2, 2, gload16(u[2], uc + U_CHUNK + 2 * U_PLANE))
+      }
       lds_barrier<1>();
     }
     {
@@ -406,8 +428,9 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
     if (active) {
       for (int c = 0; c < nkc - 1; ++c) {
         const char* vcur = smem + LDS_V0 + (c & 1) * V_STAGE + b_rd;
-        const char* un = ubase + (long)(c + 1) * U_CHUNK;
-        dma_half(min((c + 3) >> 1, ng - 1), (c + 1) & 1);   // group (c+3)/2: first half in odd c, second half in even c (a harmless re-load at the end)
+        const char* un = ubase + (long)(WF_DBG(p, 1) ? 0 : c + 1) * U_CHUNK;
+        if (!WF_DBG(p, 4)) dma_half(min((c + 3) >> 1, ng - 1), (c + 1) & 1);   // group (c+3)/2: first half in odd c, second half in even c (a harmless re-load at the end)
+        if (!WF_DBG(p, 16)) {
         WF_BLOAD(0, be0, be1)
         WF_PLANE(0, 0, 13, gload16(u[0], un))
         WF_PLANE(1, 1, 13, gload16(u[1], un + 1 * U_PLANE))
@@ -418,6 +441,8 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
         WF_PLANE(6, 6, 13, gload16(u[6], un + 6 * U_PLANE))
         WF_PLANE(7, 7, 13, gload16(u[7], un + 7 * U_PLANE))
         WF_PLANE(8, 8, 13, gload16(u[8], un + 8 * U_PLANE))
+        }
+        if (WF_DBG(p, 16)) vm_wait_plain<0>();
         vm_wait_plain<9>();                // DMA(c) has landed: only the nine reloads are younger
         lds_barrier<2>();
       }
@@ -468,8 +493,9 @@ int launch_sw(const WF& a, hipStream_t st) {
 }
 
 // `shape`: 0 = pick the super-tile shape with fewer blocks (less padding), 8 = 4 x 8 tiles, 4 = 8 x 4 tiles
-int launch(const pf_conv_params* p, const void* up, int nnb, int gs, int shape, hipStream_t st) {
+int launch(const pf_conv_params* p, const void* up, int nnb, int gs, int shape, int dbg, hipStream_t st) {
   WF a;
+  a.dbg = dbg;
   a.x = static_cast<const float*>(p->x); a.x_ld = p->x_ld; a.B = p->B; a.H = p->H; a.W = p->W; a.Cin = p->Cin;
   a.up = static_cast<const float*>(up);
   a.y = static_cast<float*>(p->y); a.y_ld = p->y_ld; a.Cout = p->Cout;
@@ -503,8 +529,9 @@ extern "C" int pf_conv_winograd_fused_supported(const pf_conv_params* p) {
 extern "C" int pf_conv_winograd_fused(const pf_conv_params* p, const void* up, int nnb, int gs, void* stream) {
   if (!p || !up || !p->x || !p->y) return PF_ERR_ARG;
   if (!pf_conv_winograd_fused_supported(p) || nnb != (p->Cout + 63) / 64) return PF_ERR_ARG;
-  // gs: low 16 bits = super-tiles per block group; bits 16.. = forced super-tile shape (8 | 4, 0 = automatic) -- tuning aid
-  return launch(p, up, nnb, gs & 0xffff, gs >> 16, reinterpret_cast<hipStream_t>(stream));
+  // gs: low 16 bits = super-tiles per block group; bits 16-19 = forced super-tile shape (8 | 4, 0 = automatic), bits 20.. = the
+  // timing-decomposition switches of WF::dbg -- tuning aids
+  return launch(p, up, nnb, gs & 0xffff, (gs >> 16) & 0xf, gs >> 20, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int pf_conv_winograd_fused_timed(const pf_conv_params* p, const void* up, int nnb, int gs, int iters, float* ms, void* stream) {

@@ -77,7 +77,8 @@ def _fused_enabled():
 def _fused_group():
     """PF_WINO_GS: super-tiles per block group (L2 locality knob); PF_WINO_SHAPE: 0 = automatic, 8 | 4 = forced super-tile width (tuning)"""
     import os
-    return (int(os.environ.get("PF_WINO_GS", "8")) & 0xffff) | (int(os.environ.get("PF_WINO_SHAPE", "0")) << 16)
+    return ((int(os.environ.get("PF_WINO_GS", "8")) & 0xffff) | (int(os.environ.get("PF_WINO_SHAPE", "0")) << 16)
+            | (int(os.environ.get("PF_WINO_DBG", "0")) << 20))     # PF_WINO_DBG: timing decomposition only (wrong results), see wino_fused.hip
 
 
 class HipOps:

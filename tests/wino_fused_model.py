@@ -115,7 +115,9 @@ def run(x, up, bias, relu, relu_in, res, res2, cout, gs=8, SW=8, conflicts=None)
                     h, cc = tc >> 2, tc & 3
                     m0, m1 = swz(sx), swz(sx + 1)
                     col = [(((4 * sy * RP + 2 * sx + (b >> 1)) * 8) + ((((b & 1) << 2) | h) ^ (m0 if b < 4 else m1))) * 16 + cc * 4 for b in range(6)]
-                    t_wr = (64 * pg + l) * 4
+                    t_wr = ((tc >> 1) * 64 + (tsl >> 4) * 32 + ((((tsl & 15) + 4 * (tc >> 1)) & 15) * 2) + (tc & 1)) * 4
+                    if conflicts is not None:
+                        banks.setdefault(('w', l >> 5), []).append((t_wr // 4) % 32)
                     d = np.empty((6, 6))
                     for a in range(6):
                         for b in range(6):
@@ -137,13 +139,17 @@ def run(x, up, bias, relu, relu_in, res, res2, cout, gs=8, SW=8, conflicts=None)
                 if n0 + half * 32 >= cout:
                     continue
                 r, g4 = lane & 15, lane >> 4
-                b_rd = (r * 8 + 2 * g4) * 4 + 9 * pg * 1024
+                b_rd = (g4 * 64 + ((r + 4 * g4) & 15) * 2) * 4 + 9 * pg * 1024
+                if conflicts is not None and kc == 0:       # ds_read2_b64: 16-lane groups, 32 banks, 2 dwords per lane
+                    for grp in range(4):
+                        bk = np.concatenate([((b_rd[16 * grp:16 * grp + 16] // 4) + e) % 32 for e in range(2)])
+                        conflicts.append(int(max(np.bincount(bk, minlength=32))))
                 ubase = ((((nb * nkc) * 36 + 9 * pg) * 2 + half) * 1024 + lane * 16) // 4
                 for P in range(9):
                     uo = ubase + (kc * U_CHUNK + P * U_PLANE) // 4
                     u = np.stack([up_f[uo + e] for e in range(4)], axis=1)        # [64, 4]
                     for tg in range(2):
-                        bo = (b_rd + P * 1024 + tg * 512) // 4
+                        bo = (b_rd + P * 1024 + tg * 128) // 4
                         bx, by = V[bo], V[bo + 1]
                         for cg in range(2):
                             a_ = acc[wave, P, tg, cg]

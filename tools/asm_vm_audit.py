@@ -9,7 +9,7 @@ is still in flight is a violation -- including a second load into it.
 
 Control flow: (1) the whole kernel is walked linearly once (prologue, peeled last chunk, epilogue: every role ends with
 vmcnt(0), so the queue is empty at the role boundaries); (2) every innermost loop that contains such loads (label .. backward
-branch, straight-line by construction) is replayed `ITER` times on its own, the queue carried from one iteration to the next,
+branch; forward branches of wave-uniform `if`s inside it are walked through) is replayed `ITER` times on its own, the queue carried from one iteration to the next,
 which reaches the steady state the hand-derived counts are written for.  The tool also reports, per loop, the vmcnt values seen
 and the deepest queue, so the expected figures (transform waves: 3 in flight / vmcnt(2); DMA waves: 16 / vmcnt(15), vmcnt(9))
 can be asserted by tests/test_kernel_resources.py.
@@ -125,13 +125,19 @@ def audit(path, name_filter="wino_fused_kernel"):
         # (2) innermost loops with asm loads, replayed
         labels = {t: i for i, (k, t) in enumerate(ins) if k == "label"}
         for i, (k, s) in enumerate(ins):
-            if k != "ins" or not s.startswith("s_cbranch"):
+            if k != "ins" or not s.startswith(("s_cbranch", "s_branch")):
                 continue
             tgt = s.split()[-1]
             if tgt in labels and labels[tgt] < i:
                 body = ins[labels[tgt]:i + 1]
-                if any(kk == "label" and tt != tgt for kk, tt in body[1:]):
-                    continue          # not innermost / not straight-line
+                nested = False        # forward branches inside the body (a wave-uniform `if`) are walked through linearly; an inner
+                for jj, (kk, tt) in enumerate(body[:-1]):       # backward branch would make this an outer loop
+                    if kk == "ins" and tt.startswith(("s_cbranch", "s_branch")):
+                        t2 = tt.split()[-1]
+                        if t2 in labels and labels[t2] <= labels[tgt] + jj:
+                            nested = True
+                if nested:
+                    continue
                 if not any(kk == "ins" and tt.startswith("global_load") for kk, tt in body):
                     continue
                 st = {"depth": 0, "loads": 0, "waits": []}

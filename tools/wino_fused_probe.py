@@ -125,8 +125,39 @@ def timing(only):
         torch.cuda.empty_cache()
 
 
+def decomp(names):
+    """timing decomposition with the kernel's debug switches (results are wrong by construction)"""
+    os.environ["PF_WINOGRAD"], os.environ["PF_WINOGRAD_MIN_PIXELS"], os.environ["PF_WINO_FUSED"] = "4", "0", "1"
+    os.environ["PF_WINO_GS"], os.environ["PF_WINO_SHAPE"] = "8", "0"
+    for name in names:
+        B, H, W, cin, cout = SHAPES[name]
+        w = torch.randn(cout, cin, 3, 3) / (9 * cin) ** 0.5
+        pw = pk.pack_conv(w, torch.zeros(cout), dtype=torch.float32).to(DEV)
+        x = torch.randn(B, H, W, cin, device=DEV)
+        y = torch.empty(B, H, W, cout, device=DEV)
+        line = f"{name}:"
+        for dbg, what in ((0, "full"), (1, "U hot"), (2, "no transform"), (4, "no DMA"), (6, "no transform, no DMA"), (7, "U hot, no transform, no DMA"),
+                          (8, "no MFMA in T waves"), (16, "no MFMA in D waves"), (24, "no MFMA at all"), (30, "barriers only"), (9, "U hot + no T MFMA"),
+                          (3, "U hot, no transform")):
+            os.environ["PF_WINO_DBG"] = str(dbg)
+            ms = ops.conv(x, pw, y, pad=1, act="relu", _timed=3)
+            line += f"\n    dbg {dbg:2d} ({what}): {ms:.3f} ms"
+        os.environ["PF_WINO_DBG"] = "0"
+        print(line, flush=True)
+
+
 if __name__ == "__main__":
     mode = sys.argv[1] if len(sys.argv) > 1 else "check"
     if mode == "check":
         sys.exit(1 if check() else 0)
+    if mode == "decomp":
+        decomp(sys.argv[2].split(",") if len(sys.argv) > 2 else ["c544_544", "c544_32"])
+        sys.exit(0)
+    if mode == "one":            # N launches of one shape (for rocprofv3 --pmc passes)
+        os.environ["PF_WINOGRAD"], os.environ["PF_WINOGRAD_MIN_PIXELS"], os.environ["PF_WINO_FUSED"] = "4", "0", os.environ.get("PF_WINO_FUSED", "1")
+        B, H, W, cin, cout = SHAPES[sys.argv[2]]
+        pw = pk.pack_conv(torch.randn(cout, cin, 3, 3) / (9 * cin) ** 0.5, torch.zeros(cout), dtype=torch.float32).to(DEV)
+        x, y = torch.randn(B, H, W, cin, device=DEV), torch.empty(B, H, W, cout, device=DEV)
+        print(sys.argv[2], ops.conv(x, pw, y, pad=1, act="relu", _timed=5), "ms")
+        sys.exit(0)
     timing(sys.argv[2].split(",") if len(sys.argv) > 2 else None)

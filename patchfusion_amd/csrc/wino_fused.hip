@@ -61,8 +61,12 @@ struct WF {
 };
 #ifdef PF_WF_DBG
 #define WF_DBG(p, bit) ((p).dbg & (bit))
+// timeline of ONE block (super-tile * nnb + channel block = 1000 * (dbg >> 8), when dbg & 128): lane 0 of every wave stores s_memtime at the marked points into
+// res2 (a long[8][256] buffer in this build): [wave][0] entry, [1] prologue done, [2 + 3c + k] points of chunk c, [250..] epilogue
+#define WF_T(idx) do { if (trec && lane == 0) reinterpret_cast<long*>(const_cast<float*>(p.res2))[wave * 256 + (idx)] = (long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define WF_DBG(p, bit) 0
+#define WF_T(idx) ((void)0)
 #endif
 
 __device__ __attribute__((aligned(256))) unsigned int wf_zero_page[64];
@@ -186,6 +190,10 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
   const int srem = sidx - b_img * (p.nsy * p.nsx);
   const int sty = srem / p.nsx, stx = srem - sty * p.nsx;
   const int n0 = nb * 64;
+#ifdef PF_WF_DBG
+  const bool trec = (p.dbg & 128) && (int)(sidx * p.nnb + nb) == (p.dbg >> 8) * 1000;
+#endif
+  WF_T(0);
   const bool active = n0 + half * 32 < p.Cout;          // (wave-uniform) this wave's 32 output channels exist
 
   // ---- DMA lanes (waves 4-7): pieces hf*20 + 5 pg + i (hf = half of the raw stage issued in this chunk interval); physical slot =
@@ -297,13 +305,13 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
         for (int cg = 0; cg < 2; ++cg)
           *reinterpret_cast<f32x4*>(smem + ((((9 * pg + i) * 32 + tg * 16 + r) * 8) + ((cg * 4 + g4) ^ (r & 7))) * 16) = acc[i][tg][cg];
   };
-  auto epi_out = [&]() {
-    // this lane's unit: tile group pg/2, channel group pg%2 -> tile T0 + 16 (pg/2) + r, channels n .. n+3
-    const int tl = (pg >> 1) * 16 + r;
-    const int q = ((pg & 1) * 4 + g4) ^ (r & 7);
-    const int n = n0 + half * 32 + (pg & 1) * 16 + 4 * g4;
-    const char* mp = smem + (tl * 8 + q) * 16;
-    float tq[4][6][4];
+  // read side of the exchange.  Unit of lane l in wave pg: tile 8 pg + l / 8, channel quad l % 8 of this half -> the eight lanes of a
+  // tile store 128 contiguous bytes per pixel (whole lines of y; the first version stored 64-byte halves of 16 different pixels per
+  // instruction and its store tail took 10.8k cycles per half).  First stage: A^T m down the columns, all 36 reads.
+  float tq[4][6][4];
+  const int etile = 8 * pg + (lane >> 3), equad = lane & 7;
+  auto epi_read = [&]() {
+    const char* mp = smem + (etile * 8 + (equad ^ (etile & 7))) * 16;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       f32x4 m[6];
@@ -319,7 +327,11 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
       }
       __builtin_amdgcn_sched_barrier(0);      // keep hipcc from hoisting all 36 reads (144 registers) above the first column
     }
-    const int ty = SH * sty + tl / SW, tx = SW * stx + tl % SW, b = b_img;
+  };
+  // second stage: along the rows, bias / ReLU / residual(s), stores
+  auto epi_store = [&]() {
+    const int n = n0 + half * 32 + 4 * equad;
+    const int ty = SH * sty + etile / SW, tx = SW * stx + etile % SW, b = b_img;
     if (ty >= p.TH || tx >= p.TW || n >= p.Cout) return;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n);
@@ -349,7 +361,7 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
           const float4 a = *reinterpret_cast<const float4*>(p.res + pix * p.res_ld + n);
           v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
         }
-        if (p.res2) {
+        if (p.res2 && !WF_DBG(p, 128)) {
           const float4 a = *reinterpret_cast<const float4*>(p.res2 + pix * p.res2_ld + n);
           v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
         }
@@ -359,6 +371,45 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
   };
   const int nkc = p.nkc;
   if (!half) {
+#ifdef PF_WF_TRING9
+    // (PF_WF_TRING9 experiment) transform waves with all nine fragments resident, like the DMA waves: 8 younger loads at every wait
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gload16(u[i], ubase + i * U_PLANE);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) vm_wait<0>(u[i]);
+    lds_barrier<1>();
+    transform_unit<ROWB>(smem, tcol, 0, smem + LDS_V0 + t_wr, lo);
+    lds_barrier<1>();
+    WF_T(1);
+    for (int c = 0; c < nkc - 1; ++c) {
+      const char* vcur = smem + LDS_V0 + (c & 1) * V_STAGE + b_rd;
+      const char* un = ubase + (long)(c + 1) * U_CHUNK;
+      WF_BLOAD(0, be0, be1)
+      WF_PLANE(0, 0, 8, gload16(u[0], un))
+      WF_PLANE(1, 1, 8, gload16(u[1], un + 1 * U_PLANE))
+      WF_PLANE(2, 2, 8, gload16(u[2], un + 2 * U_PLANE))
+      WF_PLANE(3, 3, 8, gload16(u[3], un + 3 * U_PLANE))
+      if (c < 80) WF_T(2 + 3 * c);
+      transform_unit<ROWB>(smem + (((c + 1) >> 1) & 1) * RAW_STAGE, tcol, ((c + 1) & 1) << 5, smem + LDS_V0 + ((c + 1) & 1) * V_STAGE + t_wr, lo);
+      if (c < 80) WF_T(3 + 3 * c);
+      WF_PLANE(4, 4, 8, gload16(u[4], un + 4 * U_PLANE))
+      WF_PLANE(5, 5, 8, gload16(u[5], un + 5 * U_PLANE))
+      WF_PLANE(6, 6, 8, gload16(u[6], un + 6 * U_PLANE))
+      WF_PLANE(7, 7, 8, gload16(u[7], un + 7 * U_PLANE))
+      WF_PLANE(8, 8, 8, gload16(u[8], un + 8 * U_PLANE))
+      if (c < 80) WF_T(4 + 3 * c);
+      lds_barrier<1>();
+    }
+    {
+      const char* vcur = smem + LDS_V0 + ((nkc - 1) & 1) * V_STAGE + b_rd;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) vm_wait<0>(u[i]);
+      WF_BLOAD(0, be0, be1)
+      WF_PLANE(0, 0, 0, WF_NONE) WF_PLANE(1, 1, 0, WF_NONE) WF_PLANE(2, 2, 0, WF_NONE) WF_PLANE(3, 3, 0, WF_NONE)
+      WF_PLANE(4, 4, 0, WF_NONE) WF_PLANE(5, 5, 0, WF_NONE) WF_PLANE(6, 6, 0, WF_NONE) WF_PLANE(7, 7, 0, WF_NONE)
+      WF_PLANE(8, 8, 0, WF_NONE)
+    }
+#else
     // ================= transform waves: filter fragments in a 3-deep ring (u[P % 3]); plane P's fragment is requested right after
     // plane P-3 and waited for with exactly two younger loads in flight (vmcnt(2)) =================
     gload16(u[0], ubase);
@@ -368,6 +419,7 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
     lds_barrier<1>();                                         // raw group 0 has landed (the DMA waves waited for it)
     transform_unit<ROWB>(smem, tcol, 0, smem + LDS_V0 + t_wr, lo);        // chunk 0: group 0, even
     lds_barrier<1>();
+    WF_T(1);
     for (int c = 0; c < nkc - 1; ++c) {
       const char* vcur = smem + LDS_V0 + (c & 1) * V_STAGE + b_rd;
       const char* uc = ubase + (long)(WF_DBG(p, 1) ? 0 : c) * U_CHUNK;
@@ -378,8 +430,10 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
         WF_PLANE(2, 2, 2, gload16(u[2], uc + 5 * U_PLANE))
         WF_PLANE(3, 0, 2, gload16(u[0], uc + 6 * U_PLANE))
       }
+      if (c < 80) WF_T(2 + 3 * c);
       if (!WF_DBG(p, 2))
         transform_unit<ROWB>(smem + (((c + 1) >> 1) & 1) * RAW_STAGE, tcol, ((c + 1) & 1) << 5, smem + LDS_V0 + ((c + 1) & 1) * V_STAGE + t_wr, lo);
+      if (c < 80) WF_T(3 + 3 * c);
       if (!WF_DBG(p, 8)) {
         WF_PLANE(4, 1, 2, gload16(u[1], uc + 7 * U_PLANE))
         WF_PLANE(5, 2, 2, gload16(u[2], uc + 8 * U_PLANE))
@@ -387,6 +441,7 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
         WF_PLANE(7, 1, 2, gload16(u[1], uc + U_CHUNK + U_PLANE))
         WF_PLANE(8, 2, 2, gload16(u[2], uc + U_CHUNK + 2 * U_PLANE))
       }
+      if (c < 80) WF_T(4 + 3 * c);
       lds_barrier<1>();
     }
     {
@@ -403,12 +458,19 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
       WF_PLANE(7, 1, 1, WF_NONE)
       WF_PLANE(8, 2, 0, WF_NONE)
     }
+#endif
+    WF_T(249);
     lds_barrier<1>();                                      // every wave has finished reading V; no DMA is in flight
+    WF_T(250);
     epi_write();                                           // channel half 0 first
     lds_barrier<1>();
-    epi_out();
-    lds_barrier<1>();
-    lds_barrier<1>();
+    WF_T(251);
+    epi_read();
+    lds_barrier<1>();                                      // the exchange buffer is free: the DMA waves write channel half 1 ...
+    lds_barrier<1>();                                      // (their write -> read barrier)
+    WF_T(252);
+    epi_store();                                           // ... and both halves' store tails run side by side
+    WF_T(253);
   } else {
     // ================= DMA waves: all nine fragments of a chunk stay in registers; plane P's is re-requested for the next chunk right
     // after its last MFMA.  VMEM queue when plane P waits: [u_c(P), u_c(P+1..8), DMA(c) x 5, u_{c+1}(0..P-1)] -> 13 younger
@@ -425,11 +487,18 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
     for (int i = 0; i < 9; ++i) vm_wait<0>(u[i]);
     lds_barrier<2>();
     lds_barrier<2>();
+    WF_T(1);
     if (active) {
       for (int c = 0; c < nkc - 1; ++c) {
         const char* vcur = smem + LDS_V0 + (c & 1) * V_STAGE + b_rd;
         const char* un = ubase + (long)(WF_DBG(p, 1) ? 0 : c + 1) * U_CHUNK;
+        // the DMA waves are the younger half of the block: without priority their ~50 issue-side instructions wait behind every MFMA of
+        // the co-resident transform wave (s_memtime timeline, round 3: 2250 cycles for five pieces, and 750 cycles per chunk in which
+        // NEITHER wave of the SIMD issued an MFMA)
+        __builtin_amdgcn_s_setprio(3);
         if (!WF_DBG(p, 4)) dma_half(min((c + 3) >> 1, ng - 1), (c + 1) & 1);   // group (c+3)/2: first half in odd c, second half in even c (a harmless re-load at the end)
+        __builtin_amdgcn_s_setprio(0);
+        if (c < 80) WF_T(2 + 3 * c);
         if (!WF_DBG(p, 16)) {
         WF_BLOAD(0, be0, be1)
         WF_PLANE(0, 0, 13, gload16(u[0], un))
@@ -443,7 +512,9 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
         WF_PLANE(8, 8, 13, gload16(u[8], un + 8 * U_PLANE))
         }
         if (WF_DBG(p, 16)) vm_wait_plain<0>();
+        if (c < 80) WF_T(3 + 3 * c);
         vm_wait_plain<9>();                // DMA(c) has landed: only the nine reloads are younger
+        if (c < 80) WF_T(4 + 3 * c);
         lds_barrier<2>();
       }
     } else {
@@ -465,12 +536,19 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
         WF_PLANE(8, 8, 0, WF_NONE)
       }
     }
+    WF_T(249);
     lds_barrier<2>();
     lds_barrier<2>();
     lds_barrier<2>();
+    WF_T(250);
     if (active) epi_write();                               // channel half 1
     lds_barrier<2>();
-    if (active) epi_out();
+    WF_T(251);
+    if (active) {
+      epi_read();
+      epi_store();
+    }
+    WF_T(252);
   }
 #undef WF_PLANE
 #undef WF_PLANE_

@@ -76,7 +76,7 @@ def test_fused_winograd_kernel_resources_and_hand_counted_vmem(tmp_path):
     assert listing, os.listdir(tmp_path)
     report, viol = asm_vm_audit.audit(str(tmp_path / listing[0]))
     assert not viol, viol[:5]
-    loops = [(what, st) for _, what, st, _ in report if what.startswith("loop") and st["loads"]]
+    loops = [(what, st) for _, what, st, _ in report if what.startswith("loop") and st.get("asm_loads")]
     assert len(loops) == 4, report
     shapes = sorted((st["depth"], tuple(sorted(set(st["waits"])))) for _, st in loops)
     assert shapes == [(3, (2,)), (3, (2,)), (14, (9, 13)), (14, (9, 13))], shapes

@@ -173,11 +173,9 @@ def run(x, up, bias, relu, relu_in, res, res2, cout, gs=8, SW=8, conflicts=None)
             assert not np.isnan(M).any()
             for pg in range(4):
                 for l in range(64):
-                    r, g4 = l & 15, l >> 4
-                    tl = (pg >> 1) * 16 + r
-                    q = ((pg & 1) * 4 + g4) ^ (r & 7)
-                    n = n0 + half * 32 + (pg & 1) * 16 + 4 * g4
-                    mp = (tl * 8 + q) * 16
+                    tl, equad = 8 * pg + (l >> 3), l & 7              # read side: 8 tiles x 8 channel quads per wave
+                    n = n0 + half * 32 + 4 * equad
+                    mp = (tl * 8 + (equad ^ (tl & 7))) * 16
                     m = np.empty((6, 6, 4))
                     for i in range(6):
                         for jj in range(6):

@@ -84,6 +84,7 @@ def _simulate(ins, inflight, bad, where, stats):
             inflight.append((dst, s))
             stats["depth"] = max(stats["depth"], len(inflight))
             stats["loads"] += 1
+            stats["asm_loads"] = stats.get("asm_loads", 0) + (1 if in_asm else 0)
             continue
         if op.startswith(("global_store", "buffer_store", "flat_store", "scratch_store")):
             used = _regs(s[len(op):])
@@ -138,7 +139,7 @@ def audit(path, name_filter="wino_fused_kernel"):
                             nested = True
                 if nested:
                     continue
-                if not any(kk == "ins" and tt.startswith("global_load") for kk, tt in body):
+                if not any(kk == "ins" and tt.startswith("global_load_dwordx4") for kk, tt in body):
                     continue
                 st = {"depth": 0, "loads": 0, "waits": []}
                 q = []

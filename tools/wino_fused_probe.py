@@ -146,10 +146,51 @@ def decomp(names):
         print(line, flush=True)
 
 
+def timeline(name, blocks=(1, 5)):
+    """s_memtime stamps of one block (debug build): per wave entry / prologue / per chunk (T waves: planes 0-3 done, transform done, planes
+    done; DMA waves: DMA issued, planes done, DMA landed) / epilogue phases"""
+    os.environ["PF_WINOGRAD"], os.environ["PF_WINOGRAD_MIN_PIXELS"], os.environ["PF_WINO_FUSED"] = "4", "0", "1"
+    os.environ["PF_WINO_GS"], os.environ["PF_WINO_SHAPE"] = "8", "0"
+    B, H, W, cin, cout = SHAPES[name]
+    pw = pk.pack_conv(torch.randn(cout, cin, 3, 3) / (9 * cin) ** 0.5, torch.zeros(cout), dtype=torch.float32).to(DEV)
+    x, y = torch.randn(B, H, W, cin, device=DEV), torch.empty(B, H, W, cout, device=DEV)
+    nkc = cin // 8
+    for blk in blocks:
+        tb = torch.zeros(8 * 256 * 2, dtype=torch.float32, device=DEV)
+        os.environ["PF_WINO_DBG"] = str(128 | (blk << 8))
+        ops.conv(x, pw, y, pad=1, act="relu", res2=tb.view(1, 1, 1, -1))
+        ops.conv(x, pw, y, pad=1, act="relu", res2=tb.view(1, 1, 1, -1))
+        torch.cuda.synchronize()
+        t = tb.view(torch.int64).view(8, 256).cpu()
+        t0 = int(t[:, 0][t[:, 0] > 0].min())
+        rel = lambda v: int(v) - t0 if int(v) > 0 else -1
+        print(f"{name} block {blk * 1000}: cycles relative to the first wave's entry (s_memtime ticks)")
+        for w in (0, 4):
+            role = "T" if w < 4 else "D"
+            print(f"  wave {w} ({role}): entry {rel(t[w, 0])} prologue done {rel(t[w, 1])}")
+            rows = []
+            for c in range(min(nkc - 1, 80)):
+                a, b, e = (rel(t[w, 2 + 3 * c + k]) for k in range(3))
+                rows.append((c, a, b, e))
+            for c, a, b, e in rows[:6] + rows[30:34] + rows[-3:]:
+                prev = rows[c - 1][3] if c else rel(t[w, 1])
+                if role == "T":
+                    print(f"    chunk {c:2d}: planes0-3 +{a - prev:5d}  transform +{b - a:5d}  planes4-8 +{e - b:5d}   interval {e - prev:5d}")
+                else:
+                    print(f"    chunk {c:2d}: DMA issue +{a - prev:5d}  planes +{b - a:5d}  DMA wait +{e - b:5d}   interval {e - prev:5d}")
+            iv = [rows[i][3] - rows[i - 1][3] for i in range(1, len(rows))]
+            print(f"    mean interval over chunks 1..{len(rows) - 1}: {sum(iv) / len(iv):.0f} cycles (min {min(iv)}, max {max(iv)})")
+            print(f"    last chunk done {rel(t[w, 249])}, barrier {rel(t[w, 250])}, after write+barrier {rel(t[w, 251])}, after out {rel(t[w, 252])}, end {rel(t[w, 253])}")
+    os.environ["PF_WINO_DBG"] = "0"
+
+
 if __name__ == "__main__":
     mode = sys.argv[1] if len(sys.argv) > 1 else "check"
     if mode == "check":
         sys.exit(1 if check() else 0)
+    if mode == "timeline":
+        timeline(sys.argv[2] if len(sys.argv) > 2 else "c544_544")
+        sys.exit(0)
     if mode == "decomp":
         decomp(sys.argv[2].split(",") if len(sys.argv) > 2 else ["c544_544", "c544_32"])
         sys.exit(0)

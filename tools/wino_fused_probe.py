@@ -165,22 +165,15 @@ def timeline(name, blocks=(1, 5)):
         t0 = int(t[:, 0][t[:, 0] > 0].min())
         rel = lambda v: int(v) - t0 if int(v) > 0 else -1
         print(f"{name} block {blk * 1000}: cycles relative to the first wave's entry (s_memtime ticks)")
+        for c in (30, 31):
+            print(f"  chunk {c}: absolute stamps (barrier exit, T: planes0-3 done / D: DMA issued, T: transform done / D: planes done, end before barrier)")
+            base = int(t[0, 2 + 4 * c])
+            for w in range(8):
+                print(f"    wave {w}: " + "  ".join(f"{int(t[w, 2 + 4 * c + k]) - base:6d}" for k in range(4)))
         for w in (0, 4):
-            role = "T" if w < 4 else "D"
-            print(f"  wave {w} ({role}): entry {rel(t[w, 0])} prologue done {rel(t[w, 1])}")
-            rows = []
-            for c in range(min(nkc - 1, 80)):
-                a, b, e = (rel(t[w, 2 + 3 * c + k]) for k in range(3))
-                rows.append((c, a, b, e))
-            for c, a, b, e in rows[:6] + rows[30:34] + rows[-3:]:
-                prev = rows[c - 1][3] if c else rel(t[w, 1])
-                if role == "T":
-                    print(f"    chunk {c:2d}: planes0-3 +{a - prev:5d}  transform +{b - a:5d}  planes4-8 +{e - b:5d}   interval {e - prev:5d}")
-                else:
-                    print(f"    chunk {c:2d}: DMA issue +{a - prev:5d}  planes +{b - a:5d}  DMA wait +{e - b:5d}   interval {e - prev:5d}")
-            iv = [rows[i][3] - rows[i - 1][3] for i in range(1, len(rows))]
-            print(f"    mean interval over chunks 1..{len(rows) - 1}: {sum(iv) / len(iv):.0f} cycles (min {min(iv)}, max {max(iv)})")
-            print(f"    last chunk done {rel(t[w, 249])}, barrier {rel(t[w, 250])}, after write+barrier {rel(t[w, 251])}, after out {rel(t[w, 252])}, end {rel(t[w, 253])}")
+            iv = [int(t[w, 2 + 4 * (c + 1)]) - int(t[w, 2 + 4 * c]) for c in range(2, 58)]
+            print(f"  wave {w}: mean interval chunks 2..57: {sum(iv) / len(iv):.0f} cycles")
+            print(f"    prologue done {rel(t[w, 1])}, last chunk done {rel(t[w, 249])}, barrier {rel(t[w, 250])}, after write+barrier {rel(t[w, 251])}, {rel(t[w, 252])}, end {rel(t[w, 253])}")
     os.environ["PF_WINO_DBG"] = "0"
 
 

@@ -212,7 +212,7 @@ def gemm_sweep(dtype, dev, only=()):
 
 def kernel_source_sha():
     h = hashlib.sha256()
-    for f in ("igemm.hip", "pf_common.h"):
+    for f in ("igemm.hip", "wino_fused.hip", "pf_common.h"):
         with open(os.path.join(ROOT, "patchfusion_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:12]
@@ -246,6 +246,30 @@ def roofline(dtype, dev, gemm_only=False):
     except Exception:
         pass
     direct_flops = 2.0 * B * H * W * 9 * C * C
+    from patchfusion_amd import hip_ops
+    if pw.wino_up is not None and pk.winograd_applies(pw, B * H * W, 1, 1, "relu") and hip_ops._fused_wanted(B, H, W, C, C):
+        # round 3: the layer is ONE kernel (csrc/wino_fused.hip): its own multiply-adds = 36 transform points x 2 x T x C x C with
+        # T = B * ceil(H/4) * ceil(W/4) output tiles (the padding tiles of the 4x8 super-tiles are not counted), priced against the
+        # f32 MFMA peak; the kernel also does both transforms and the epilogue, so kernel == layer
+        T = B * -(-H // 4) * -(-W // 4)
+        x = torch.randn(B, H, W, C, device=dev)
+        y = torch.empty(B, H, W, C, device=dev)
+        ms = ops.conv(x, pw, y, pad=1, act="relu", _timed=5)
+        flops = 36 * 2.0 * T * C * C
+        ach = flops / (ms * 1e-3) / 1e12
+        try:
+            with open(os.path.join(ROOT, "profiles", "r3_pmc_dominant_fp32.json")) as f:
+                j = json.load(f)
+            traffic = j["derived"]["traffic_bytes"] if j.get("kernel_source_sha") == kernel_source_sha() else None
+        except Exception:
+            traffic = None
+        return {"bound": "mfma",
+                "kernel": f"wino_fused_kernel (v_mfma_f32_16x16x4_f32): fused Winograd F(4x4,3x3) of the largest layer, 3x3 {C}->{C} @ {B}x{H}x{W} "
+                          f"(GuidedFusion up-conv): input transform + 36 x [{T} x {C}].[{C} x {C}] + output transform + epilogue in one launch",
+                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "traffic": traffic, "winograd_m": 4,
+                "layer": {"what": "kernel == whole layer (no separate transform passes)", "ms": round(ms, 4),
+                          "direct_conv_flops": direct_flops, "direct_conv_tflops_equivalent": round(direct_flops / (ms * 1e-3) / 1e12, 2)}}
     if pw.wino_u is not None and pk.winograd_applies(pw, B * H * W, 1, 1, "relu"):
         m = pw.wino_m
         a2 = (m + 2) ** 2
@@ -310,9 +334,15 @@ def cpu_baseline(cfg, sd, img):
         orc._predict(crop, box, tile_cfg, 1)
         dt = time.perf_counter() - t0
     log(f"cpu baseline: one tile (fine branch + fusion) {dt:.1f}s on {cores} threads")
-    return {"value": round(1.0 / dt, 5), "unit": "patches/s", "cores": cores, "kind": "port",
-            "sample": f"1 tile (fine branch + fusion, 4029.9 GFLOP, G2L hoisted) of the same DA-vitl 392x518 workload: "
-                      f"{dt:.1f} s on {cores} threads"}
+    out = {"value": round(1.0 / dt, 5), "unit": "patches/s", "cores": cores, "kind": "port",
+           "sample": f"1 tile (fine branch + fusion, 4029.9 GFLOP, G2L hoisted) of the same DA-vitl 392x518 workload: "
+                     f"{dt:.1f} s on {cores} threads"}
+    try:      # the reference's OWN code cannot run on the GPU box (/root/reference is absent there): the figure recorded in the build container
+        with open(os.path.join(ROOT, "profiles", "r3_cpu_reference.json")) as f:
+            out["reference_recorded"] = json.load(f)
+    except Exception:
+        pass
+    return out
 
 
 def _cpu_baseline_reference(cfg, sd, img, cores):

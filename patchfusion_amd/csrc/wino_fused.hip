@@ -25,10 +25,14 @@
 //           and y is stored once.
 // Per 8-channel chunk a block issues 576 MFMAs (4608 cycles per SIMD) against 19 KiB of input halo and 72 KiB of filter fragments.
 //
-// Wave roles (8 waves, two per SIMD: wave w and w+4).  Waves 0-3 (channel half 0): planes 0-3, rows 0-2 of the next chunk's input
-// transform (VALU + LDS only), planes 4-8.  Waves 4-7 (channel half 1): 5 LDS-DMA pieces each (half a raw stage per chunk) first, planes
-// 0-5, rows 3-5 of the transform, planes 6-8.  With f32 MFMA the co-resident wave's VALU work does not overlap the matrix pipe, so the
-// non-MFMA work is split evenly between the two waves of a SIMD and placed at different points of the chunk.
+// Measured on the way and NOT kept (round 3, gpurun_out/r3*_wf_time.log, r3j_variants.log): 8 channels (2 x 16 B) per pixel and chunk in the raw
+// stage (v1: same speed -- the L1 fill of partial lines was not the limiter); one `s_mov m0` for five DMA pieces through the instruction
+// offset, which shifts the global AND the LDS address (+4 %: five back-to-back VMEM issues stall the wave longer than five spread ones);
+// the input transform split over all eight waves, output rows 0-2 / 3-5 (+4 %: the DMA waves, already the younger half in the issue
+// arbitration, became the critical path); s_setprio around the DMA issue (+-0).
+// Wave roles (8 waves, two per SIMD: wave w and w+4).  Waves 0-3 ("transform", channel half 0): planes 0-3, the input transform of
+// the next chunk (VALU + LDS only), planes 4-8.  Waves 4-7 ("DMA", channel half 1): 5 LDS-DMA pieces each (half a raw stage per
+// chunk) first, then planes 0-8.  The two waves of a SIMD are therefore never both outside their MFMA stream.
 // One barrier per chunk.  Global loads and the DMA are issued from inline asm and counted by hand (s_waitcnt vmcnt(N) naming the
 // registers it releases, like the hand-counted LDS reads of igemm.hip); tools/asm_vm_audit.py replays the in-order VMEM queue over the
 // emitted assembly (tests/test_kernel_resources.py).  tests/wino_fused_model.py replays every index formula below lane by lane.
@@ -70,30 +74,18 @@ struct WF {
 #define WF_T(idx) ((void)0)
 #endif
 
-// 8 KiB of zeros: the source of every out-of-image 16-byte vector; the biased pointers of glds16x5 reach +-2 KiB around its middle
-__device__ __attribute__((aligned(256))) unsigned int wf_zero_page[2048];
+__device__ __attribute__((aligned(256))) unsigned int wf_zero_page[64];
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
 }
-// Five LDS-DMA pieces (1 KiB each: 16 bytes per lane) under ONE M0: the instruction offset shifts BOTH the global and the LDS address,
-// so piece i (i = 0..4) is issued with offset (i-2)*1024 from M0 = the middle piece's LDS address and a per-lane pointer that was
-// biased by -(i-2)*1024 beforehand.  (Round-3 s_memtime timeline: with one `s_mov m0` per piece the five pieces of a chunk took ~2500
-// cycles to issue -- an M0 write waits for the LDS-DMA instructions ahead of it.)  M0 is saved / restored inside the statement
-// (cdna_hip_programming.md 5.7).
-__device__ __forceinline__ void glds16x5(const void* p0, const void* p1, const void* p2, const void* p3, const void* p4, unsigned lds_mid) {
+// LDS-DMA of 16 bytes per lane (see igemm.hip glds16; cdna_hip_programming.md 5.7)
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
   unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, off offset:-2048\n\t"
-      "global_load_lds_dwordx4 %2, off offset:-1024\n\t"
-      "global_load_lds_dwordx4 %3, off\n\t"
-      "global_load_lds_dwordx4 %4, off offset:1024\n\t"
-      "global_load_lds_dwordx4 %5, off offset:2048\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "s"(lds_mid)
-      : "memory");
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
 }
 // global -> register load hipcc does not see (no s_waitcnt bookkeeping): the destination is tied ("+v") so that the register
 // stays ONE live range through the chunk loop; vm_wait<N> names it again before the first MFMA that reads it.
@@ -142,40 +134,36 @@ __device__ __forceinline__ void at6(const float (&m)[6], float (&o)[4]) {
 // reads then hit 8 distinct slots = 32 distinct banks.
 __device__ __forceinline__ int swz(int sx) { return ((sx & 1) << 2) | (sx & 2); }
 
-// HALF of the input transform of one (tile, channel) unit: output rows 3 HALF .. 3 HALF + 2 of B^T d B = planes 18 HALF .. 18 HALF + 17.
-// 30 LDS reads at raw + (col[b] ^ jx) + a*ROWB (rows 0-2 need input rows 0..4, rows 3-5 input rows 1..5), 6 + 6 operations per column
-// and 12 per output row, 18 LDS writes at vout + plane*1024.  Every wave of the block runs one half: the transform's VALU work does
-// not overlap the co-resident wave's f32 MFMAs (round-3 s_memtime timeline), so it is split evenly between the two waves of a SIMD.
-template <int ROWB, int HALF>
-__device__ __forceinline__ void transform_half(const char* raw, const int (&col)[6], int jx, char* vout, bool relu_in) {
-  float t[3][6];
+// input transform of one (tile, channel) unit: 36 LDS reads at raw + (col[b] ^ jx) + a*ROWB, B^T d B, 36 LDS writes at vout + k*1024
+template <int ROWB>
+__device__ __forceinline__ void transform_unit(const char* raw, const int (&col)[6], int jx, char* vout, bool relu_in) {
+  float d[6][6];
 #pragma unroll
   for (int b = 0; b < 6; ++b) {
-    const char* cp = raw + (col[b] ^ jx) + HALF * ROWB;
-    float d[5];                                      // input rows HALF .. HALF + 4
+    const char* cp = raw + (col[b] ^ jx);
 #pragma unroll
-    for (int a = 0; a < 5; ++a) d[a] = *reinterpret_cast<const float*>(cp + a * ROWB);
-    if (relu_in) {                                   // (wave-uniform) ResidualConvUnit: ReLU on load
+    for (int a = 0; a < 6; ++a) d[a][b] = *reinterpret_cast<const float*>(cp + a * ROWB);
+  }
+  if (relu_in) {                                    // (wave-uniform) ResidualConvUnit: ReLU on load
 #pragma unroll
-      for (int a = 0; a < 5; ++a) d[a] = fmaxf(d[a], 0.f);
-    }
-    if constexpr (HALF == 0) {                       // rows 0, 1, 2 of B^T d from d0..d4
-      const float pp = fmaf(-4.f, d[2], d[4]), qq = fmaf(-4.f, d[1], d[3]);
-      t[0][b] = fmaf(4.f, d[0], fmaf(-5.f, d[2], d[4]));
-      t[1][b] = pp + qq;
-      t[2][b] = pp - qq;
-    } else {                                         // rows 3, 4, 5 from d1..d5 (held in d[0..4])
-      const float rr = d[3] - d[1], ss = d[2] - d[0];
-      t[0][b] = fmaf(2.f, ss, rr);
-      t[1][b] = fmaf(-2.f, ss, rr);
-      t[2][b] = fmaf(4.f, d[0], fmaf(-5.f, d[2], d[4]));
-    }
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = 0; b < 6; ++b) d[a][b] = fmaxf(d[a][b], 0.f);
   }
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {                      // (B^T d) B : along the rows
-    bt6(t[r]);
+  for (int b = 0; b < 6; ++b) {                     // B^T d : down the columns
+    float c6[6];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) *reinterpret_cast<float*>(vout + ((3 * HALF + r) * 6 + j) * 1024) = t[r][j];
+    for (int a = 0; a < 6; ++a) c6[a] = d[a][b];
+    bt6(c6);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) d[a][b] = c6[a];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {                     // (B^T d) B : along the rows
+    bt6(d[i]);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) *reinterpret_cast<float*>(vout + (i * 6 + j) * 1024) = d[i][j];
   }
 }
 
@@ -231,21 +219,20 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
       }
     }
   }
-  const char* zero = reinterpret_cast<const char*>(wf_zero_page) + 4096;
+  const char* zero = reinterpret_cast<const char*>(wf_zero_page);
   const float* __restrict__ xg = p.x;
   // half `hf` (0 | 1) of the raw stage of channel group G (16 channels = chunks 2G, 2G+1) -> stage G & 1
   auto dma_half = [&](int G, int hf) {
-    const unsigned mid = smem_base + (G & 1) * RAW_STAGE + (hf * 20 + 5 * pg + 2) * 1024;
-    const char* src[5];
+    const unsigned dst = smem_base + (G & 1) * RAW_STAGE + (hf * 20 + 5 * pg) * 1024;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       const int o = hf ? doff[5 + i] : doff[i];
-      src[i] = (o >= 0 ? reinterpret_cast<const char*>(xg + (long)o + G * 16) : zero) - (i - 2) * 1024;
+      const char* src = o >= 0 ? reinterpret_cast<const char*>(xg + (long)o + G * 16) : zero;
+      glds16(src, dst + i * 1024);
     }
-    glds16x5(src[0], src[1], src[2], src[3], src[4], mid);
   };
 
-  // ---- transform lanes (all waves: waves 0-3 output rows 0-2, waves 4-7 rows 3-5): unit = (tile slot 8 pg + lane/8, channel lane%8 of the chunk); col[b] = byte offset of raw
+  // ---- transform lanes (waves 0-3): unit = (tile slot 8 pg + lane/8, channel lane%8 of the chunk); col[b] = byte offset of raw
   // pixel (4 sy, 4 sx + b), channel quad h of an EVEN chunk (odd chunks: ^ 32), + 4 cc ----
   const int tc = lane & 7, tsl = 8 * pg + (lane >> 3);
   int tcol[6];
@@ -389,38 +376,35 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
   };
   const int nkc = p.nkc;
   if (!half) {
-    // ================= waves 0-3: channel half 0, transform rows 0-2.  All nine filter fragments of a chunk stay in registers; plane P's
-    // is re-requested for the next chunk right after its last MFMA: [u_c(P), u_c(P+1..8), u_{c+1}(0..P-1)] -> 8 younger loads at every wait
+    // ================= transform waves (0-3): all nine filter fragments of a chunk stay in registers; plane P's is re-requested for the next
+    // chunk right after its last MFMA: VMEM queue when plane P waits = [u_c(P), u_c(P+1..8), u_{c+1}(0..P-1)] -> 8 younger loads.
+    // (A 3-deep ring u[P % 3] with vmcnt(2) measured 0.5 % slower at gs 8 and 3-5 % slower at larger block groups: the two planes
+    // between request and use are shorter than the L2 latency whenever this wave has the matrix pipe to itself.) =================
 #pragma unroll
     for (int i = 0; i < 9; ++i) gload16(u[i], ubase + i * U_PLANE);
 #pragma unroll
     for (int i = 0; i < 9; ++i) vm_wait<0>(u[i]);
-    lds_barrier<1>();                                         // raw group 0 has landed (the DMA waves waited for it)
-    transform_half<ROWB, 0>(smem, tcol, 0, smem + LDS_V0 + t_wr, lo);     // chunk 0: group 0, even
+    lds_barrier<1>();
+    transform_unit<ROWB>(smem, tcol, 0, smem + LDS_V0 + t_wr, lo);
     lds_barrier<1>();
     WF_T(1);
     for (int c = 0; c < nkc - 1; ++c) {
       const char* vcur = smem + LDS_V0 + (c & 1) * V_STAGE + b_rd;
-      const char* un = ubase + (long)(WF_DBG(p, 1) ? 0 : c + 1) * U_CHUNK;
+      const char* un = ubase + (long)(c + 1) * U_CHUNK;
       if (c < 60) WF_T(2 + 4 * c);
-      if (!WF_DBG(p, 8)) {
-        WF_BLOAD(0, be0, be1)
-        WF_PLANE(0, 0, 8, gload16(u[0], un))
-        WF_PLANE(1, 1, 8, gload16(u[1], un + 1 * U_PLANE))
-        WF_PLANE(2, 2, 8, gload16(u[2], un + 2 * U_PLANE))
-        WF_PLANE(3, 3, 8, gload16(u[3], un + 3 * U_PLANE))
-      }
+      WF_BLOAD(0, be0, be1)
+      WF_PLANE(0, 0, 8, gload16(u[0], un))
+      WF_PLANE(1, 1, 8, gload16(u[1], un + 1 * U_PLANE))
+      WF_PLANE(2, 2, 8, gload16(u[2], un + 2 * U_PLANE))
+      WF_PLANE(3, 3, 8, gload16(u[3], un + 3 * U_PLANE))
       if (c < 60) WF_T(3 + 4 * c);
-      if (!WF_DBG(p, 2))
-        transform_half<ROWB, 0>(smem + (((c + 1) >> 1) & 1) * RAW_STAGE, tcol, ((c + 1) & 1) << 5, smem + LDS_V0 + ((c + 1) & 1) * V_STAGE + t_wr, lo);
+      transform_unit<ROWB>(smem + (((c + 1) >> 1) & 1) * RAW_STAGE, tcol, ((c + 1) & 1) << 5, smem + LDS_V0 + ((c + 1) & 1) * V_STAGE + t_wr, lo);
       if (c < 60) WF_T(4 + 4 * c);
-      if (!WF_DBG(p, 8)) {
-        WF_PLANE(4, 4, 8, gload16(u[4], un + 4 * U_PLANE))
-        WF_PLANE(5, 5, 8, gload16(u[5], un + 5 * U_PLANE))
-        WF_PLANE(6, 6, 8, gload16(u[6], un + 6 * U_PLANE))
-        WF_PLANE(7, 7, 8, gload16(u[7], un + 7 * U_PLANE))
-        WF_PLANE(8, 8, 8, gload16(u[8], un + 8 * U_PLANE))
-      }
+      WF_PLANE(4, 4, 8, gload16(u[4], un + 4 * U_PLANE))
+      WF_PLANE(5, 5, 8, gload16(u[5], un + 5 * U_PLANE))
+      WF_PLANE(6, 6, 8, gload16(u[6], un + 6 * U_PLANE))
+      WF_PLANE(7, 7, 8, gload16(u[7], un + 7 * U_PLANE))
+      WF_PLANE(8, 8, 8, gload16(u[8], un + 8 * U_PLANE))
       if (c < 60) WF_T(5 + 4 * c);
       lds_barrier<1>();
     }
@@ -460,7 +444,6 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) vm_wait<0>(u[i]);
     lds_barrier<2>();
-    transform_half<ROWB, 1>(smem, tcol, 0, smem + LDS_V0 + t_wr, lo);     // chunk 0, rows 3-5
     lds_barrier<2>();
     WF_T(1);
     if (active) {
@@ -483,10 +466,6 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
         WF_PLANE(3, 3, 13, gload16(u[3], un + 3 * U_PLANE))
         WF_PLANE(4, 4, 13, gload16(u[4], un + 4 * U_PLANE))
         WF_PLANE(5, 5, 13, gload16(u[5], un + 5 * U_PLANE))
-        }
-        if (!WF_DBG(p, 2))
-          transform_half<ROWB, 1>(smem + (((c + 1) >> 1) & 1) * RAW_STAGE, tcol, ((c + 1) & 1) << 5, smem + LDS_V0 + ((c + 1) & 1) * V_STAGE + t_wr, lo);
-        if (!WF_DBG(p, 16)) {
         WF_PLANE(6, 6, 13, gload16(u[6], un + 6 * U_PLANE))
         WF_PLANE(7, 7, 13, gload16(u[7], un + 7 * U_PLANE))
         WF_PLANE(8, 8, 13, gload16(u[8], un + 8 * U_PLANE))
@@ -501,7 +480,6 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const WF p) {
       // the upper channel half does not exist (last channel block of a layer with Cout % 64 == 32): this wave only feeds the DMA
       for (int c = 0; c < nkc - 1; ++c) {
         dma_half(min((c + 3) >> 1, ng - 1), (c + 1) & 1);
-        transform_half<ROWB, 1>(smem + (((c + 1) >> 1) & 1) * RAW_STAGE, tcol, ((c + 1) & 1) << 5, smem + LDS_V0 + ((c + 1) & 1) * V_STAGE + t_wr, lo);
         vm_wait_plain<0>();
         lds_barrier<2>();
       }

@@ -68,10 +68,38 @@ def _ld(t):
     return ld
 
 
-def _fused_enabled():
-    """PF_WINO_FUSED (read per call): 1 (default) = eligible F(4x4,3x3) layers take the fused kernel, 0 = the three-step path"""
+def _fused_wanted(B, H, W, cin, cout):
+    """PF_WINO_FUSED (read per call): 0 = three-step path only, 2 = the fused kernel for every layer it supports, 1 (default) = the
+    measured rule (profiles/r3_wino_fused_time.log, 1x MI355X): the fused kernel wins wherever it has at least two rounds of blocks
+    and the layer is not 768+ -> 768+ channels (there the batched GEMM's 128x64 tiles re-use the filters better: 0.95-0.98x), i.e.
+    1.01x (544->544 @ 8x392x518) ... 1.2-1.7x (256/512 -> 128/256 channels) ... 2.0-2.4x (-> 32 channels) of the three-step time."""
     import os
-    return os.environ.get("PF_WINO_FUSED", "1") != "0"
+    mode = os.environ.get("PF_WINO_FUSED", "1")
+    if mode == "0":
+        return False
+    if mode == "2":
+        return True
+    th, tw = -(-H // 4), -(-W // 4)
+    nsuper = B * min(-(-th // 4) * -(-tw // 8), -(-th // 8) * -(-tw // 4))
+    return nsuper * -(-cout // 64) >= 512 and not (cin >= 768 and cout >= 768)
+
+
+_WS = {}
+
+
+def _workspace(device, nV, nM):
+    """V / M workspaces of the three-step Winograd path, one growing pair per (device, stream): launches of one stream are ordered, so
+    the pair can be reused by every layer of that stream instead of 2 x 8 GB of fresh allocations per call (round-2 advisor finding)."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    v, m = _WS.get(key, (None, None))
+    if v is None or v.numel() < nV:
+        v = None
+        v = torch.empty(nV, dtype=torch.float32, device=device)
+    if m is None or m.numel() < nM:
+        m = None
+        m = torch.empty(nM, dtype=torch.float32, device=device)
+    _WS[key] = (v, m)
+    return v, m
 
 
 def _fused_group():
@@ -127,7 +155,7 @@ class HipOps:
             ms = C.c_float(0)
             check(_L.pf_conv_timed(C.byref(p), int(_timed), C.byref(ms), _stream()), "pf_conv_timed")
             return ms.value
-        if wino and pw.wino_up is not None and _fused_enabled() and _L.pf_conv_winograd_fused_supported(C.byref(p)):
+        if wino and pw.wino_up is not None and _fused_wanted(B, H, W, pw.cin, pw.cout) and _L.pf_conv_winograd_fused_supported(C.byref(p)):
             # fused F(4x4,3x3): one kernel, no V / M workspaces (csrc/wino_fused.hip)
             assert y4.dtype == torch.float32 and (res is None or res.dtype == torch.float32) and (res2 is None or res2.dtype == torch.float32)
             _p(pw.wino_up)
@@ -145,8 +173,7 @@ class HipOps:
             T = B * -(-H // m) * -(-W // m)
             a2 = (m + 2) ** 2
             assert y4.dtype == torch.float32 and (res is None or res.dtype == torch.float32) and (res2 is None or res2.dtype == torch.float32)
-            V = torch.empty(a2 * T * pw.cin, dtype=torch.float32, device=x4.device)
-            Mw = torch.empty(a2 * T * pw.cout, dtype=torch.float32, device=x4.device)
+            V, Mw = _workspace(x4.device, a2 * T * pw.cin, a2 * T * pw.cout)
 
             def run():
                 check(_L.pf_conv_winograd(C.byref(p), m, _p(pw.wino_u), pw.wino_u.shape[1], pw.wino_u.shape[2], _p(V), _p(Mw), _stream()),

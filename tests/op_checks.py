@@ -134,7 +134,7 @@ def conv_winograd_fused(dt):
             r1 = _rand((B, H, W, cout), torch.float32, 300 + i) if kw.get("res") else None
             r2 = _rand((B, H, W, cout + 8), torch.float32, 400 + i)[..., :cout] if kw.get("res2") else None
             outs = []
-            for o, direct, fused in ((hip(), None, "1"), (hip(), None, "0"), (ref_ops, True, "0")):
+            for o, direct, fused in ((hip(), None, "2"), (hip(), None, "0"), (ref_ops, True, "0")):
                 os.environ["PF_WINO_FUSED"] = fused
                 yb = torch.zeros((B, H, W, cout + 16), dtype=torch.float32, device=DEV)
                 o.conv(x, pw, yb[..., 8:8 + cout], pad=1, act=kw.get("act"), relu_in=kw.get("relu_in", False), res=r1, res2=r2, _direct=direct)

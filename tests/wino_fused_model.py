@@ -104,12 +104,10 @@ def run(x, up, bias, relu, relu_in, res, res2, cout, gs=8, SW=8, conflicts=None)
                         for l in range(64):
                             o = doff[pg, i, l]
                             raw[dst + 4 * l: dst + 4 * l + 4] = xf[o + 16 * G: o + 16 * G + 4] if o >= 0 else 0.0
-            # ---- transform: EVERY wave, unit = (tile slot 8 pg + lane/8, channel lane%8 of this chunk); waves 0-3 produce output rows 0-2
-            # (planes 0..17, from input rows 0..4), waves 4-7 rows 3-5 (planes 18..35, from input rows 1..5)
-            V = np.full(V_STAGE // 4, np.nan)
+            # ---- transform (waves 0-3): unit = (tile slot 8 pg + lane/8, channel lane%8 of this chunk)
+            V = np.zeros(V_STAGE // 4)
             jx = j << 5
-            for wave in range(8):
-                pg, HALF = wave & 3, wave >> 2
+            for pg in range(4):
                 banks = {}
                 for l in range(64):
                     tc, tsl = l & 7, 8 * pg + (l >> 3)
@@ -120,23 +118,21 @@ def run(x, up, bias, relu, relu_in, res, res2, cout, gs=8, SW=8, conflicts=None)
                     t_wr = ((tc >> 1) * 64 + (tsl >> 4) * 32 + ((((tsl & 15) + 4 * (tc >> 1)) & 15) * 2) + (tc & 1)) * 4
                     if conflicts is not None:
                         banks.setdefault(('w', l >> 5), []).append((t_wr // 4) % 32)
-                    d = np.zeros((6, 6))
-                    for a in range(HALF, HALF + 5):
+                    d = np.empty((6, 6))
+                    for a in range(6):
                         for b in range(6):
                             adr = (col[b] ^ jx) + a * ROWB
                             v = raw[adr // 4]
-                            assert not np.isnan(v), (wave, l, a, b)
+                            assert not np.isnan(v), (pg, l, a, b)
                             d[a, b] = max(v, 0.0) if relu_in else v
                             if conflicts is not None:
                                 banks.setdefault((a, b, l >> 5), []).append((adr // 4) % 32)
-                    assert np.all(BT[3 * HALF:3 * HALF + 3, 5 * (1 - HALF)] == 0)      # the skipped input row has zero weight
-                    v = BT[3 * HALF:3 * HALF + 3] @ d @ BT.T
-                    for r in range(3):
+                    v = BT @ d @ BT.T
+                    for i in range(6):
                         for jj in range(6):
-                            V[(t_wr + ((3 * HALF + r) * 6 + jj) * 1024) // 4] = v[r, jj]
+                            V[(t_wr + (i * 6 + jj) * 1024) // 4] = v[i, jj]
                 if conflicts is not None:
                     conflicts.append(max(max(np.bincount(np.array(bk), minlength=32)) for bk in banks.values()))
-            assert not np.isnan(V).any()
             # ---- MFMA (all waves)
             for wave in range(8):
                 pg, half = wave & 3, wave >> 2

@@ -57,7 +57,7 @@ def check():
             r1 = rand((B, H, W, cout), 300 + i) if kw.get("res") else None
             r2 = rand((B, H, W, cout + 8), 400 + i)[..., :cout] if kw.get("res2") else None
             outs = []
-            for o, direct, fused in ((ops, None, "1"), (ref_ops, True, "0")):
+            for o, direct, fused in ((ops, None, "2"), (ref_ops, True, "0")):
                 os.environ["PF_WINO_FUSED"] = fused
                 yb = torch.zeros((B, H, W, cout + 16), dtype=torch.float32, device=DEV)
                 o.conv(x, pw, yb[..., 8:8 + cout], pad=1, act=kw.get("act"), relu_in=kw.get("relu_in", False), res=r1, res2=r2, _direct=direct)
@@ -110,7 +110,7 @@ def timing(only):
         os.environ["PF_WINO_FUSED"] = "0"
         ms3 = ops.conv(x, pw, y, pad=1, act="relu", _timed=3)
         line = f"{name:14s} B{B} {H}x{W} {cin}->{cout}: three-step {ms3:8.3f} ms ({fl_d / ms3 / 1e9:6.1f} TF/s direct-eq) | fused"
-        os.environ["PF_WINO_FUSED"] = "1"
+        os.environ["PF_WINO_FUSED"] = "2"
         best = None
         for gs, shp in ((1, 0), (4, 0), (8, 0), (16, 0), (64, 0), (8, 8), (8, 4)):
             os.environ["PF_WINO_GS"], os.environ["PF_WINO_SHAPE"] = str(gs), str(shp)
@@ -127,7 +127,7 @@ def timing(only):
 
 def decomp(names):
     """timing decomposition with the kernel's debug switches (results are wrong by construction)"""
-    os.environ["PF_WINOGRAD"], os.environ["PF_WINOGRAD_MIN_PIXELS"], os.environ["PF_WINO_FUSED"] = "4", "0", "1"
+    os.environ["PF_WINOGRAD"], os.environ["PF_WINOGRAD_MIN_PIXELS"], os.environ["PF_WINO_FUSED"] = "4", "0", "2"
     os.environ["PF_WINO_GS"], os.environ["PF_WINO_SHAPE"] = "8", "0"
     for name in names:
         B, H, W, cin, cout = SHAPES[name]
@@ -149,7 +149,7 @@ def decomp(names):
 def timeline(name, blocks=(1, 5)):
     """s_memtime stamps of one block (debug build): per wave entry / prologue / per chunk (T waves: planes 0-3 done, transform done, planes
     done; DMA waves: DMA issued, planes done, DMA landed) / epilogue phases"""
-    os.environ["PF_WINOGRAD"], os.environ["PF_WINOGRAD_MIN_PIXELS"], os.environ["PF_WINO_FUSED"] = "4", "0", "1"
+    os.environ["PF_WINOGRAD"], os.environ["PF_WINOGRAD_MIN_PIXELS"], os.environ["PF_WINO_FUSED"] = "4", "0", "2"
     os.environ["PF_WINO_GS"], os.environ["PF_WINO_SHAPE"] = "8", "0"
     B, H, W, cin, cout = SHAPES[name]
     pw = pk.pack_conv(torch.randn(cout, cin, 3, 3) / (9 * cin) ** 0.5, torch.zeros(cout), dtype=torch.float32).to(DEV)
@@ -188,7 +188,7 @@ if __name__ == "__main__":
         decomp(sys.argv[2].split(",") if len(sys.argv) > 2 else ["c544_544", "c544_32"])
         sys.exit(0)
     if mode == "one":            # N launches of one shape (for rocprofv3 --pmc passes)
-        os.environ["PF_WINOGRAD"], os.environ["PF_WINOGRAD_MIN_PIXELS"], os.environ["PF_WINO_FUSED"] = "4", "0", os.environ.get("PF_WINO_FUSED", "1")
+        os.environ["PF_WINOGRAD"], os.environ["PF_WINOGRAD_MIN_PIXELS"], os.environ["PF_WINO_FUSED"] = "4", "0", os.environ.get("PF_WINO_FUSED", "2")
         B, H, W, cin, cout = SHAPES[sys.argv[2]]
         pw = pk.pack_conv(torch.randn(cout, cin, 3, 3) / (9 * cin) ** 0.5, torch.zeros(cout), dtype=torch.float32).to(DEV)
         x, y = torch.randn(B, H, W, cin, device=DEV), torch.empty(B, H, W, cout, device=DEV)

@@ -105,6 +105,10 @@ int pf_qkv_split(const void* qkv, int B, int S, int Hh, void* q, void* k, void* 
  * Replaces dinov2/layers/attention.py:53-59 (the materialised N x N scores). */
 int pf_vit_attention(const void* q, const void* k, const void* vt, void* out, int B, int S, int Sp, int Hh,
                      int dtype, void* stream);
+/* float32 attention straight from the QKV GEMM's rows [B*S][3][Hh][64] (no pf_qkv_split, no Q / K / V^T buffers): softmax(q k^T / 8) v
+ * per head, head_dim 64, out [B*S][Hh*64].  Same reference lines as pf_vit_attention (dinov2/layers/attention.py:49-62); base-2 softmax
+ * with the hardware exponential (relative error ~1e-7 per probability).  dtype must be PF_DTYPE_F32. */
+int pf_vit_attention_qkv(const void* qkv, void* out, int B, int S, int Hh, int dtype, void* stream);
 
 /* ---- G2L (Swin window attention) -------------------------------------------------------------- */
 /* LayerNorm(norm1) -> zero pad to a multiple of 12 -> cyclic shift -> window partition

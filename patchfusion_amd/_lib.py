@@ -41,6 +41,7 @@ SIGNATURES = {
     "pf_layernorm": [vp, ci, vp, ci, vp, vp, cf, ci, ci, ci, ci, ci, ci, vp],
     "pf_qkv_split": [vp, ci, ci, ci, vp, vp, vp, ci, cf, ci, vp],
     "pf_vit_attention": [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
+    "pf_vit_attention_qkv": [vp, vp, ci, ci, ci, ci, vp],
     "pf_swin_ln_partition": [vp, ci, vp, vp, vp, cf, ci, ci, ci, ci, ci, ci, vp],
     "pf_swin_window_attention": [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp],
     "pf_swin_unpartition_add": [vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp],

@@ -1,6 +1,7 @@
 // ViT (DINOv2) encoder kernels other than the linear layers (those run on igemm.hip):
 // patch im2col + ImageNet normalisation, token assembly, LayerNorm, qkv head split and the fused
 // softmax attention on the matrix cores.
+#include <type_traits>
 #include "pf_common.h"
 #include "../../include/pf_hip.h"
 
@@ -487,6 +488,187 @@ __global__ __launch_bounds__(256) void vit_attention32_kernel(const bf16_t* __re
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// f32 attention, version 2 (round 3): reads Q, K, V STRAIGHT from the QKV GEMM's output rows [B*S][3][Hh][64] -- no qkv_split
+// launch, no Q / K / V^T buffers -- and spends far fewer VALU instructions per key tile.  With v_mfma_f32_16x16x4_f32 the VALU work
+// of a SIMD does not overlap its matrix pipe (they serialise: round-3 s_memtime timelines of csrc/wino_fused.hip), so the 526 VALU
+// instructions per 64-key tile of vit_attention_kernel<float> (full-precision expf, per-score key masking) cost as much pipe time as
+// half of the tile's 128 MFMAs.  Here: scores in the base-2 domain (Q is scaled by head_dim^-1/2 * log2 e when its fragments are
+// loaded; one v_exp_f32 per score), key masking only in the last tile (wave-uniform branch), V transposed on its way into LDS
+// (global [key][d] -> LDS [d][key], 4-byte stores) so that the P.V fragment reads stay 16-byte.
+// Same structure otherwise: block = 4 waves x 16 queries, S^T = K Q^T so that a lane's 16 scores belong to ONE query, online softmax
+// with f32 statistics, O^T = V^T P^T.
+// ---------------------------------------------------------------------------------------------
+template <int QG>      // query groups of 16 per wave: a block covers 64 QG queries; the K / V^T fragments are read once for all groups
+__global__ __launch_bounds__(256, QG == 1 ? 3 : 2) void vit_attention_qkv_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, int B, int S,
+                                                                     int Hh, float qscale) {
+  constexpr int ROWB = 256;
+  __shared__ __attribute__((aligned(16))) char lds[2 * 64 * ROWB];
+  char* Ks = lds;                       // [key][d]  16-byte slot ^ (key & 15)
+  char* Vs = lds + 64 * ROWB;           // [d][key]  16-byte slot ^ vswz(d)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.y, b = bh / Hh, h = bh % Hh;
+  const int q0 = blockIdx.x * (64 * QG) + wave * (16 * QG);
+  const bool has_q = q0 < S;                                       // (wave-uniform) the last query block of S = 1037 keeps one wave of four
+  const int D = Hh * 64;
+  const long rs = 3L * D;                                          // row stride of the qkv matrix
+  const float* base = qkv + (long)b * S * rs + h * 64;             // + s * rs (+ D for K, + 2 D for V)
+
+  float4 qf[QG][4];
+#pragma unroll
+  for (int qg = 0; qg < QG; ++qg) {
+    const int qi = min(q0 + qg * 16 + r, S - 1);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      qf[qg][s4] = *reinterpret_cast<const float4*>(base + (long)qi * rs + s4 * 16 + g * 4);
+      qf[qg][s4].x *= qscale; qf[qg][s4].y *= qscale; qf[qg][s4].z *= qscale; qf[qg][s4].w *= qscale;
+    }
+  }
+  f32x4 o[QG][4];
+  float m_run[QG], l_run[QG];
+#pragma unroll
+  for (int qg = 0; qg < QG; ++qg) {
+    m_run[qg] = -INFINITY;
+    l_run[qg] = 0.f;
+#pragma unroll
+    for (int fd = 0; fd < 4; ++fd) o[qg][fd] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int ntiles = (S + 63) / 64;
+  const int nf_last = (S - (ntiles - 1) * 64 + 15) >> 4;           // 16-key fragments of the last tile that hold keys (1037: one of four)
+  // staging: 64 keys x 16 vectors of 4 floats per matrix; thread -> vector sj = tid % 16 of keys srr0 + 16 i.
+  // V^T swizzle vswz(d) = (d & 15) ^ ((d >> 4) & 3): a bijection of d & 15 for the 16-row fragment reads (conflict free) that also
+  // spreads the transposing 4-byte stores (d = 4 sj + e over the 16 lanes of a key) over 8 slots instead of 2 (PMC of the first
+  // version: 53 % of the LDS cycles were bank conflicts)
+  const int sj = tid & 15, srr0 = tid >> 4;
+  float4 kreg[4], vreg[4];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int key = kt * 64 + srr0 + 16 * i;
+      const float* rp = base + (long)min(key, S - 1) * rs + sj * 4;
+      const float4 kv = *reinterpret_cast<const float4*>(rp + D);
+      const float4 vv = *reinterpret_cast<const float4*>(rp + 2 * D);
+      const bool ok = key < S;
+      kreg[i] = ok ? kv : make_float4(0.f, 0.f, 0.f, 0.f);
+      vreg[i] = ok ? vv : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  // one key tile for this wave's 16 QG queries: FULL (no masking, four fragments) or the last tile (nfr fragments, masked)
+  auto tile = [&](int kt, auto full_c, int nfr) {
+    constexpr bool FULL = decltype(full_c)::value;
+    // ---- S^T = K Q^T (base-2 logits): 4 QG independent accumulator chains, round-robin ----
+    f32x4 sc[QG][4];
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) sc[qg][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      float4 a[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) a[f] = *reinterpret_cast<const float4*>(Ks + (f * 16 + r) * ROWB + (((s4 * 4 + g) ^ r) << 4));
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          if (!FULL && f >= nfr) continue;
+          const float av = e == 0 ? a[f].x : e == 1 ? a[f].y : e == 2 ? a[f].z : a[f].w;
+#pragma unroll
+          for (int qg = 0; qg < QG; ++qg) {
+            const float qv = e == 0 ? qf[qg][s4].x : e == 1 ? qf[qg][s4].y : e == 2 ? qf[qg][s4].z : qf[qg][s4].w;
+            sc[qg][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, qv, sc[qg][f], 0, 0, 0);
+          }
+        }
+    }
+    // ---- online softmax for query (group qg, lane & 15); this lane holds keys kt*64 + f*16 + g*4 + e ----
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+      if (!FULL) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (kt * 64 + f * 16 + g * 4 + e >= S) sc[qg][f][e] = -INFINITY;
+      }
+      float mx = fmaxf(fmaxf(fmaxf(sc[qg][0][0], sc[qg][0][1]), fmaxf(sc[qg][0][2], sc[qg][0][3])),
+                       fmaxf(fmaxf(sc[qg][1][0], sc[qg][1][1]), fmaxf(sc[qg][1][2], sc[qg][1][3])));
+      mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(sc[qg][2][0], sc[qg][2][1]), fmaxf(sc[qg][2][2], sc[qg][2][3])),
+                           fmaxf(fmaxf(sc[qg][3][0], sc[qg][3][1]), fmaxf(sc[qg][3][2], sc[qg][3][3]))));
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[qg], mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[qg] - m_new);
+      m_run[qg] = m_new;
+      float psum = 0.f;
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pe = __builtin_amdgcn_exp2f(sc[qg][f][e] - m_new);
+          sc[qg][f][e] = pe;
+          psum += pe;
+        }
+      l_run[qg] = l_run[qg] * alpha + psum;
+#pragma unroll
+      for (int fd = 0; fd < 4; ++fd)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[qg][fd][e] *= alpha;
+    }
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      if (!FULL && f >= nfr) continue;
+      float4 a[4];
+#pragma unroll
+      for (int fd = 0; fd < 4; ++fd) a[fd] = *reinterpret_cast<const float4*>(Vs + (fd * 16 + r) * ROWB + (((f * 4 + g) ^ r ^ fd) << 4));
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int fd = 0; fd < 4; ++fd) {
+          const float av = e == 0 ? a[fd].x : e == 1 ? a[fd].y : e == 2 ? a[fd].z : a[fd].w;
+#pragma unroll
+          for (int qg = 0; qg < QG; ++qg) o[qg][fd] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, sc[qg][f][e], o[qg][fd], 0, 0, 0);
+        }
+    }
+  };
+  gload(0);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    __syncthreads();                                      // every wave has finished reading tile kt-1
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int key = srr0 + 16 * i;                      // row of K, column of V^T
+      *reinterpret_cast<float4*>(Ks + key * ROWB + ((sj ^ (key & 15)) << 4)) = kreg[i];
+      const float ve[4] = {vreg[i].x, vreg[i].y, vreg[i].z, vreg[i].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int d = sj * 4 + e;
+        *reinterpret_cast<float*>(Vs + d * ROWB + (((key >> 2) ^ (d & 15) ^ ((d >> 4) & 3)) << 4) + (key & 3) * 4) = ve[e];
+      }
+    }
+    __syncthreads();
+    if (kt + 1 < ntiles) gload(kt + 1);
+    if (has_q) {
+      if (kt + 1 < ntiles) tile(kt, std::true_type{}, 4);
+      else tile(kt, std::false_type{}, nf_last);
+    }
+  }
+#pragma unroll
+  for (int qg = 0; qg < QG; ++qg) {
+    float l = l_run[qg];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    const int qo = q0 + qg * 16 + r;
+    if (qo < S) {
+      float* dst = out + ((long)b * S + qo) * D + h * 64 + g * 4;
+#pragma unroll
+      for (int fd = 0; fd < 4; ++fd) store4(dst + fd * 16, o[qg][fd][0] * inv, o[qg][fd][1] * inv, o[qg][fd][2] * inv, o[qg][fd][3] * inv);
+    }
+  }
+}
+
 inline int grid_for(long n, int block) {
   long g = (n + block - 1) / block;
   return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
@@ -543,5 +725,19 @@ extern "C" int pf_vit_attention(const void* q, const void* k, const void* vt, vo
   if (dtype == PF_DTYPE_BF16 && !old_attn) hipLaunchKernelGGL(vit_attention32_kernel, dim3((S + 127) / 128, B * Hh), dim3(256), 0, ST(stream), (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, B, S, Sp, Hh);
   else if (dtype == PF_DTYPE_BF16) hipLaunchKernelGGL(vit_attention_kernel<bf16_t>, grid, dim3(256), 0, ST(stream), (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, B, S, Sp, Hh);
   else hipLaunchKernelGGL(vit_attention_kernel<float>, grid, dim3(256), 0, ST(stream), (const float*)q, (const float*)k, (const float*)vt, (float*)out, B, S, Sp, Hh);
+  return ok();
+}
+
+extern "C" int pf_vit_attention_qkv(const void* qkv, void* out, int B, int S, int Hh, int dtype, void* stream) {
+  if (!qkv || !out || B <= 0 || S <= 0 || Hh <= 0 || dtype != PF_DTYPE_F32) return PF_ERR_ARG;
+  // head_dim^-1/2 (attention.py:55, 64^-1/2) times log2(e): the kernel's softmax runs on base-2 logits
+  const float qscale = 0.125f * 1.4426950408889634f;
+  // 16 queries per wave, three blocks per CU (default).  PF_ATTN_QG=2: 32 queries per wave -- the K / V^T fragments and the staging of a
+  // key tile serve twice the MFMAs, but at 230 registers only two blocks fit a CU: measured 436 vs 391 us at B8 S1037 (round 3), kept
+  // for A/B measurements only
+  static int qg = -1;
+  if (qg < 0) { const char* e = getenv("PF_ATTN_QG"); qg = (e && e[0] == '2') ? 2 : 1; }
+  if (qg == 2) hipLaunchKernelGGL(vit_attention_qkv_f32_kernel<2>, dim3((S + 127) / 128, B * Hh), dim3(256), 0, ST(stream), (const float*)qkv, (float*)out, B, S, Hh, qscale);
+  else hipLaunchKernelGGL(vit_attention_qkv_f32_kernel<1>, dim3((S + 63) / 64, B * Hh), dim3(256), 0, ST(stream), (const float*)qkv, (float*)out, B, S, Hh, qscale);
   return ok();
 }

@@ -238,6 +238,11 @@ class HipOps:
         """qkv [B*S, 3*D] -> out [B*S, D]; head_dim must be 64."""
         D = qkv.shape[1] // 3
         assert D == heads * 64 and qkv.is_contiguous() and out.is_contiguous()
+        import os
+        if qkv.dtype == torch.float32 and os.environ.get("PF_ATTN_QKV", "1") != "0":
+            # f32: the attention kernel reads q / k / v rows straight out of the QKV GEMM's output (csrc/vit.hip, version 2)
+            check(_L.pf_vit_attention_qkv(_p(qkv), _p(out), B, S, heads, 0, _stream()), "pf_vit_attention_qkv")
+            return
         Sp = (S + 63) // 64 * 64
         q = torch.empty((B, heads, S, 64), dtype=qkv.dtype, device=qkv.device)
         k = torch.empty_like(q)

@@ -362,6 +362,21 @@ def vit_attention(dt):
     return max(errs), _tol(dt, 1e-4, 2e-2), "vit attention"
 
 
+def vit_attention_split(dt):
+    """float32: the round-2 pair pf_qkv_split + pf_vit_attention (PF_ATTN_QKV=0) stays covered next to the version-2 kernel that reads the
+    QKV rows directly (the default, checked by vit_attention above)"""
+    import os
+    old = os.environ.get("PF_ATTN_QKV")
+    os.environ["PF_ATTN_QKV"] = "0"
+    try:
+        return vit_attention(dt)
+    finally:
+        if old is None:
+            os.environ.pop("PF_ATTN_QKV", None)
+        else:
+            os.environ["PF_ATTN_QKV"] = old
+
+
 def swin_ops(dt):
     errs = []
     for (B, H, W, C, heads) in ((1, 14, 19, 64, 32), (1, 28, 37, 64, 16), (2, 30, 25, 32, 8), (1, 13, 24, 256, 8), (1, 12, 12, 128, 8), (1, 17, 12, 256, 16), (1, 12, 24, 64, 8)):
@@ -559,8 +574,8 @@ CHECKS = {
     "conv_split_n272_res_views": conv_split_n272_res_views, "conv_split_gemm_n544_inplace": conv_split_gemm_n544_inplace,
     "conv_gemm_vitl_linear_shape": conv_gemm_vitl_linear_shape, "conv_dominant_launch": conv_dominant_launch,
     "conv_transpose": conv_transpose, "patch_embed_tokens": patch_embed_tokens, "layernorm": layernorm,
-    "vit_attention": vit_attention, "swin_ops": swin_ops, "resize_ops": resize_ops, "roi_ops": roi_ops,
+    "vit_attention": vit_attention, "vit_attention_split": vit_attention_split, "swin_ops": swin_ops, "resize_ops": resize_ops, "roi_ops": roi_ops,
     "conv_winograd": conv_winograd, "conv_winograd_fused": conv_winograd_fused, "misc_ops": misc_ops, "bins_ops": bins_ops, "stitch_ops": stitch_ops,
 }
-F32_ONLY = {"bins_ops", "stitch_ops", "conv_winograd", "conv_winograd_fused"}
+F32_ONLY = {"bins_ops", "stitch_ops", "conv_winograd", "conv_winograd_fused", "vit_attention_split"}
 DTYPES = {"fp32": torch.float32, "bf16": torch.bfloat16}

@@ -85,6 +85,22 @@ int pf_conv_winograd_fused(const pf_conv_params* p, const void* up, int nnb, int
 /* timing helper like pf_conv_timed: `iters` launches bracketed by HIP events on `stream` */
 int pf_conv_winograd_fused_timed(const pf_conv_params* p, const void* up, int nnb, int gs, int iters, float* ms, void* stream);
 
+/* ---- split-precision linear layer ("f32x3", exploratory mode; csrc/gemm_split3.hip) --------------------------------------------
+ * float32-grade y = epi(x . w^T) on the bf16 matrix cores: x and w are given as THREE bf16 planes each (x = x_h + x_m + x_l, round-to-
+ * nearest splits) and the six leading partial products are accumulated in float32.  `p` as for pf_conv with KH = KW = 1: x = planes
+ * [3][M][x_ld] bf16 (plane stride x_bstride elements), w = planes [3][w_rows][Kpad] bf16 (w_bstride; packing.pack_conv_split3), Cin % 32
+ * == 0, bias / scale / res / res2 float32; y = float32 [M][y_ld] when out_f32 != 0, else three bf16 planes [3][M][y_ld] (y_bstride) for a
+ * following split GEMM.  Same reference layers as pf_conv's linear use (attention.py:51,60, mlp.py:35-41). */
+int pf_gemm_split3(const pf_conv_params* p, void* stream);
+int pf_gemm_split3_timed(const pf_conv_params* p, int iters, float* ms, void* stream);
+/* the split producers of the ViT block: LayerNorm (layers/block.py:88-93 norm1 / norm2) and the attention output (attention.py:58-60)
+ * written as three bf16 planes; arguments as pf_layernorm (plain row range) / pf_vit_attention_qkv with the plane stride in elements */
+int pf_layernorm_split3(const float* x, int x_ld, void* y3, int y_ld, long plane, const float* g, const float* b, float eps, long rows,
+                        int D, void* stream);
+int pf_vit_attention_qkv_split3(const void* qkv, void* out3, long plane, int B, int S, int Hh, void* stream);
+/* float32 [rows][x_ld] -> three bf16 planes [3][rows][y_ld], plane stride `plane` elements (the split producers fuse into their stores) */
+int pf_split3(const float* x, int x_ld, void* y, int y_ld, long plane, long rows, int cols, void* stream);
+
 /* ---- ViT encoder pieces ---------------------------------------------------------------------- */
 /* (x - mean)/std + 14x14/14 patch gather: NCHW float image -> im2col rows [B*th*tw][ld] (K order
  * ky,kx,c).  Replaces depth_anything.py:184-190 (Normalize) + the unfold implied by patch_embed.py:76 */

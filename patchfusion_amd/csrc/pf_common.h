@@ -76,6 +76,23 @@ __device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, flo
   r.y = (uint32_t)f2bf(c) | ((uint32_t)f2bf(d) << 16);
   *reinterpret_cast<uint2*>(p) = r;
 }
+
+// split-precision ("f32x3") producers, csrc/gemm_split3.hip: x = h + m + l in three bf16 planes `plane` elements apart
+__device__ __forceinline__ void store_split3(bf16_t* y, long plane, const float (&v)[4]) {
+#pragma clang fp contract(off)      // v - h must subtract the ROUNDED value v, not fuse with the multiply that produced it
+  uint32_t h[4], m[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h[i] = f2bf(v[i]);
+    const float r1 = v[i] - bf2f((bf16_t)h[i]);
+    m[i] = f2bf(r1);
+    l[i] = f2bf(r1 - bf2f((bf16_t)m[i]));
+  }
+  *reinterpret_cast<uint2*>(y) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+  *reinterpret_cast<uint2*>(y + plane) = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
+  *reinterpret_cast<uint2*>(y + 2 * plane) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+}
+
 __device__ __forceinline__ void load4(const float* p, float (&v)[4]) {
   float4 a = *reinterpret_cast<const float4*>(p);
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;

@@ -93,6 +93,51 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
   }
 }
 
+// LayerNorm of float32 rows with the output as three bf16 planes (x = h + m + l) for the split-precision GEMM (csrc/gemm_split3.hip)
+__global__ __launch_bounds__(256) void layernorm_split3_kernel(const float* __restrict__ x, int x_ld, bf16_t* __restrict__ y, int y_ld, long plane,
+                                                               const float* __restrict__ g, const float* __restrict__ bta, float eps, long rows, int D) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * x_ld;
+  bf16_t* yr = y + row * y_ld;
+  const int nv = D >> 3;
+  float v[4][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int vi = lane + 64 * i;
+    if (vi < nv) {
+      load8(xr + vi * 8, v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[i][e];
+    }
+  }
+  const float mean = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int vi = lane + 64 * i;
+    if (vi < nv) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int vi = lane + 64 * i;
+    if (vi < nv) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * g[vi * 8 + e] + bta[vi * 8 + e];
+      const float lo[4] = {o[0], o[1], o[2], o[3]}, hi[4] = {o[4], o[5], o[6], o[7]};
+      store_split3(yr + vi * 8, plane, lo);
+      store_split3(yr + vi * 8 + 4, plane, hi);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // qkv split: qkv [B*S][3][Hh][64] -> Q*scale [B,Hh,S,64], K [B,Hh,S,64], V^T [B,Hh,64,Sp]
 // grid (ceil(S/64), B*Hh), 256 threads.
@@ -501,7 +546,7 @@ __global__ __launch_bounds__(256) void vit_attention32_kernel(const bf16_t* __re
 // ---------------------------------------------------------------------------------------------
 template <int QG>      // query groups of 16 per wave: a block covers 64 QG queries; the K / V^T fragments are read once for all groups
 __global__ __launch_bounds__(256, QG == 1 ? 3 : 2) void vit_attention_qkv_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, int B, int S,
-                                                                     int Hh, float qscale) {
+                                                                     int Hh, float qscale, long plane) {
   constexpr int ROWB = 256;
   __shared__ __attribute__((aligned(16))) char lds[2 * 64 * ROWB];
   char* Ks = lds;                       // [key][d]  16-byte slot ^ (key & 15)
@@ -662,9 +707,18 @@ __global__ __launch_bounds__(256, QG == 1 ? 3 : 2) void vit_attention_qkv_f32_ke
     const float inv = 1.0f / l;
     const int qo = q0 + qg * 16 + r;
     if (qo < S) {
-      float* dst = out + ((long)b * S + qo) * D + h * 64 + g * 4;
+      const long at = ((long)b * S + qo) * D + h * 64 + g * 4;
+      if (plane) {                  // out = three bf16 planes for the split-precision projection GEMM (csrc/gemm_split3.hip)
 #pragma unroll
-      for (int fd = 0; fd < 4; ++fd) store4(dst + fd * 16, o[qg][fd][0] * inv, o[qg][fd][1] * inv, o[qg][fd][2] * inv, o[qg][fd][3] * inv);
+        for (int fd = 0; fd < 4; ++fd) {
+          const float w4[4] = {o[qg][fd][0] * inv, o[qg][fd][1] * inv, o[qg][fd][2] * inv, o[qg][fd][3] * inv};
+          store_split3(reinterpret_cast<bf16_t*>(out) + at + fd * 16, plane, w4);
+        }
+      } else {
+        float* dst = out + at;
+#pragma unroll
+        for (int fd = 0; fd < 4; ++fd) store4(dst + fd * 16, o[qg][fd][0] * inv, o[qg][fd][1] * inv, o[qg][fd][2] * inv, o[qg][fd][3] * inv);
+      }
     }
   }
 }
@@ -728,8 +782,7 @@ extern "C" int pf_vit_attention(const void* q, const void* k, const void* vt, vo
   return ok();
 }
 
-extern "C" int pf_vit_attention_qkv(const void* qkv, void* out, int B, int S, int Hh, int dtype, void* stream) {
-  if (!qkv || !out || B <= 0 || S <= 0 || Hh <= 0 || dtype != PF_DTYPE_F32) return PF_ERR_ARG;
+static int attention_qkv(const void* qkv, void* out, long plane, int B, int S, int Hh, void* stream) {
   // head_dim^-1/2 (attention.py:55, 64^-1/2) times log2(e): the kernel's softmax runs on base-2 logits
   const float qscale = 0.125f * 1.4426950408889634f;
   // 16 queries per wave, three blocks per CU (default).  PF_ATTN_QG=2: 32 queries per wave -- the K / V^T fragments and the staging of a
@@ -737,7 +790,24 @@ extern "C" int pf_vit_attention_qkv(const void* qkv, void* out, int B, int S, in
   // for A/B measurements only
   static int qg = -1;
   if (qg < 0) { const char* e = getenv("PF_ATTN_QG"); qg = (e && e[0] == '2') ? 2 : 1; }
-  if (qg == 2) hipLaunchKernelGGL(vit_attention_qkv_f32_kernel<2>, dim3((S + 127) / 128, B * Hh), dim3(256), 0, ST(stream), (const float*)qkv, (float*)out, B, S, Hh, qscale);
-  else hipLaunchKernelGGL(vit_attention_qkv_f32_kernel<1>, dim3((S + 63) / 64, B * Hh), dim3(256), 0, ST(stream), (const float*)qkv, (float*)out, B, S, Hh, qscale);
+  if (qg == 2) hipLaunchKernelGGL(vit_attention_qkv_f32_kernel<2>, dim3((S + 127) / 128, B * Hh), dim3(256), 0, ST(stream), (const float*)qkv, (float*)out, B, S, Hh, qscale, plane);
+  else hipLaunchKernelGGL(vit_attention_qkv_f32_kernel<1>, dim3((S + 63) / 64, B * Hh), dim3(256), 0, ST(stream), (const float*)qkv, (float*)out, B, S, Hh, qscale, plane);
+  return ok();
+}
+
+extern "C" int pf_vit_attention_qkv(const void* qkv, void* out, int B, int S, int Hh, int dtype, void* stream) {
+  if (!qkv || !out || B <= 0 || S <= 0 || Hh <= 0 || dtype != PF_DTYPE_F32) return PF_ERR_ARG;
+  return attention_qkv(qkv, out, 0, B, S, Hh, stream);
+}
+
+extern "C" int pf_vit_attention_qkv_split3(const void* qkv, void* out3, long plane, int B, int S, int Hh, void* stream) {
+  if (!qkv || !out3 || B <= 0 || S <= 0 || Hh <= 0 || plane < (long)B * S * Hh * 64) return PF_ERR_ARG;
+  return attention_qkv(qkv, out3, plane, B, S, Hh, stream);
+}
+
+extern "C" int pf_layernorm_split3(const float* x, int x_ld, void* y3, int y_ld, long plane, const float* g, const float* b, float eps,
+                                   long rows, int D, void* stream) {
+  if (!x || !y3 || !g || !b || D % 8 || D > 2048 || x_ld % 8 || y_ld % 8 || rows <= 0 || plane < (rows - 1) * y_ld + D) return PF_ERR_ARG;
+  hipLaunchKernelGGL(layernorm_split3_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST(stream), x, x_ld, (bf16_t*)y3, y_ld, plane, g, b, eps, rows, D);
   return ok();
 }

@@ -25,6 +25,12 @@ from .spec import DPT_ARCH, VIT_ARCH, branch_channels
 F32 = torch.float32
 
 
+def linear_split3_enabled():
+    """float32 mode: run the ViT block linears as split-precision GEMMs (csrc/gemm_split3.hip)?  PF_LINEAR_SPLIT3=0 / 1; default on"""
+    import os
+    return os.environ.get("PF_LINEAR_SPLIT3", "1") != "0"
+
+
 def _g(sd, name, device):
     return sd[name].detach().to(device=device, dtype=F32).contiguous()
 
@@ -150,6 +156,15 @@ class BranchNet:
                                cin_total=592).to(dev)
         self.pos = pk.vit_pos_embed(sd[v + "pos_embed"], self.th, self.tw).to(dev)
         self.cls = _g(sd, v + "cls_token", dev).reshape(-1)
+        # float32 compute: the encoder's four linear layers per block run as split-precision GEMMs on the bf16 matrix cores (x = h + m + l,
+        # six partial products, float32 accumulation: csrc/gemm_split3.hip; float32-grade error, measured against float64 in
+        # tests/op_checks.py gemm_split3).  PF_LINEAR_SPLIT3=0 keeps them on the float32 MFMA.
+        self.split3 = dtype == F32 and linear_split3_enabled()
+        if self.split3:
+            def pc(name, bias=True, _pc=pc, **kw):           # (only the block linears below are re-routed)
+                if ".blocks." in name:
+                    return pk.pack_conv_split3(sd[name + ".weight"], sd[name + ".bias"] if bias else None, **kw).to(dev)
+                return _pc(name, bias, **kw)
         self.blocks = []
         for i in range(self.depth):
             b = f"{v}blocks.{i}."
@@ -221,14 +236,25 @@ class BranchNet:
         qkv = ops.empty((B * S, 3 * D), dt, dev)
         att = ops.empty((B * S, D), dt, dev)
         mid = ops.empty((B * S, 4 * D), dt, dev)
+        if self.split3:                                            # operands of the split GEMMs travel as three bf16 planes
+            hbuf, att, mid = (ops.empty((3, B * S, n), torch.bfloat16, dev) for n in (D, D, 4 * D))
         for i, blk in enumerate(self.blocks):
-            ops.layernorm(x, hbuf, blk["n1"][0], blk["n1"][1], 1e-6)
-            ops.conv(hbuf, blk["qkv"], qkv)
-            ops.vit_attention(qkv, att, B, S, self.heads)
-            ops.conv(att, blk["proj"], x, res=x)                   # x += ls1 * proj(attn)
-            ops.layernorm(x, hbuf, blk["n2"][0], blk["n2"][1], 1e-6)
-            ops.conv(hbuf, blk["fc1"], mid, act="gelu")
-            ops.conv(mid, blk["fc2"], x, res=x)                    # x += ls2 * fc2(gelu(fc1))
+            if self.split3:
+                ops.layernorm_split3(x, hbuf, blk["n1"][0], blk["n1"][1], 1e-6)
+                ops.conv_split3(hbuf, blk["qkv"], qkv)
+                ops.vit_attention(qkv, att, B, S, self.heads)
+                ops.conv_split3(att, blk["proj"], x, res=x)
+                ops.layernorm_split3(x, hbuf, blk["n2"][0], blk["n2"][1], 1e-6)
+                ops.conv_split3(hbuf, blk["fc1"], mid, act="gelu")
+                ops.conv_split3(mid, blk["fc2"], x, res=x)
+            else:
+                ops.layernorm(x, hbuf, blk["n1"][0], blk["n1"][1], 1e-6)
+                ops.conv(hbuf, blk["qkv"], qkv)
+                ops.vit_attention(qkv, att, B, S, self.heads)
+                ops.conv(att, blk["proj"], x, res=x)                   # x += ls1 * proj(attn)
+                ops.layernorm(x, hbuf, blk["n2"][0], blk["n2"][1], 1e-6)
+                ops.conv(hbuf, blk["fc1"], mid, act="gelu")
+                ops.conv(mid, blk["fc2"], x, res=x)                    # x += ls2 * fc2(gelu(fc1))
             if taps is not None and i in (0, self.depth - 1):
                 taps[f"vit_block{i}"] = x.view(B, S, D).clone()
             if i >= self.depth - 4:

@@ -210,6 +210,51 @@ class HipOps:
         check(_L.pf_conv_timed(C.byref(p), int(iters), C.byref(ms), _stream()), "pf_conv_timed")
         return ms.value
 
+    # ---------------- split-precision GEMM (exploratory "f32x3" mode) ----------------
+    @staticmethod
+    def split3(x, y3):
+        """x float32 [M, K] (row stride >= K) -> y3 bfloat16 [3, M, K] planes"""
+        assert x.dtype == torch.float32 and y3.dtype == torch.bfloat16 and y3.dim() == 3 and y3.shape[0] == 3 and y3.is_contiguous()
+        M, K = x.shape
+        check(_L.pf_split3(_p(x), x.stride(0), _p(y3), y3.stride(1), y3.stride(0), M, K, _stream()), "pf_split3")
+        return y3
+
+    @staticmethod
+    def conv_split3(x3, pw: PackedConv, y, act=None, res=None, res2=None, _timed=None):
+        """x3 bfloat16 [3, M, K] planes; pw from packing.pack_conv_split3; y float32 [M, N] or bfloat16 [3, M, N] planes (split output);
+        res / res2 float32 [M, N].  float32-grade linear layer on the bf16 matrix cores (csrc/gemm_split3.hip)."""
+        assert x3.dtype == torch.bfloat16 and x3.dim() == 3 and x3.shape[0] == 3 and x3.stride(2) == 1 and pw.w.dtype == torch.bfloat16
+        M = x3.shape[1]
+        split_out = y.dtype == torch.bfloat16
+        p = ConvParams()
+        p.x, p.x_ld, p.B, p.H, p.W, p.Cin = x3.data_ptr(), x3.stride(1), 1, 1, M, pw.cin
+        p.x_bstride = x3.stride(0)
+        p.w, p.w_rows, p.Kpad, p.w_bstride = pw.w.data_ptr(), pw.w.shape[1], pw.w.shape[2], pw.w.stride(0)
+        p.bias = pw.bias.data_ptr() if pw.bias is not None else None
+        p.scale = pw.scale.data_ptr() if pw.scale is not None else None
+        p.res = res.data_ptr() if res is not None else None
+        p.res_ld = res.stride(-2) if res is not None else 0
+        p.res2 = res2.data_ptr() if res2 is not None else None
+        p.res2_ld = res2.stride(-2) if res2 is not None else 0
+        if split_out:
+            assert y.dim() == 3 and y.shape[0] == 3 and y.shape[1] == M and y.stride(2) == 1
+            p.y, p.y_ld, p.y_bstride, p.out_f32 = y.data_ptr(), y.stride(1), y.stride(0), 0
+        else:
+            assert y.dtype == torch.float32 and y.stride(-1) == 1
+            p.y, p.y_ld, p.out_f32 = y.data_ptr(), y.stride(-2), 1
+        p.OH, p.OW, p.Cout = 1, M, pw.cout
+        p.KH = p.KW = p.stride = 1
+        p.act, p.shuffle, p.dtype = ACT[act], 1, 1
+        for t in (x3, y, pw.w, res, res2):
+            _p(t)
+            assert t is None or t is x3 or t is y or t is pw.w or t.dtype == torch.float32
+        if _timed is not None:
+            ms = C.c_float(0)
+            check(_L.pf_gemm_split3_timed(C.byref(p), int(_timed), C.byref(ms), _stream()), "pf_gemm_split3_timed")
+            return ms.value
+        check(_L.pf_gemm_split3(C.byref(p), _stream()), "pf_gemm_split3")
+        return y
+
     # ---------------- ViT ----------------
     @staticmethod
     def patch_im2col(img, out):
@@ -234,11 +279,26 @@ class HipOps:
                               in_row_offset, out_rows_per_batch, D, _dt(x), _stream()), "pf_layernorm")
 
     @staticmethod
+    def layernorm_split3(x, y3, g, b, eps):
+        """LayerNorm of float32 rows x [M, D], output as three bfloat16 planes y3 [3, M, D] (input of ops.conv_split3)"""
+        assert x.dtype == torch.float32 and y3.dtype == torch.bfloat16 and y3.dim() == 3 and y3.shape[0] == 3 and y3.stride(2) == 1
+        M, D = x.shape
+        assert y3.shape[1] == M and y3.shape[2] == D
+        check(_L.pf_layernorm_split3(_p(x), x.stride(0), _p(y3), y3.stride(1), y3.stride(0), _p(g), _p(b), float(eps), M, D, _stream()),
+              "pf_layernorm_split3")
+        return y3
+
+    @staticmethod
     def vit_attention(qkv, out, B, S, heads):
-        """qkv [B*S, 3*D] -> out [B*S, D]; head_dim must be 64."""
+        """qkv [B*S, 3*D] -> out [B*S, D]; head_dim must be 64.  float32 qkv with a bfloat16 out [3, B*S, D]: the output is written as
+        the three split planes of the projection GEMM (ops.conv_split3)."""
         D = qkv.shape[1] // 3
         assert D == heads * 64 and qkv.is_contiguous() and out.is_contiguous()
         import os
+        if qkv.dtype == torch.float32 and out.dtype == torch.bfloat16:
+            assert tuple(out.shape) == (3, B * S, D)
+            check(_L.pf_vit_attention_qkv_split3(_p(qkv), _p(out), out.stride(0), B, S, heads, _stream()), "pf_vit_attention_qkv_split3")
+            return
         if qkv.dtype == torch.float32 and os.environ.get("PF_ATTN_QKV", "1") != "0":
             # f32: the attention kernel reads q / k / v rows straight out of the QKV GEMM's output (csrc/vit.hip, version 2)
             check(_L.pf_vit_attention_qkv(_p(qkv), _p(out), B, S, heads, 0, _stream()), "pf_vit_attention_qkv")

@@ -175,6 +175,41 @@ def pack_conv(weight, bias=None, *, dtype, cin_map=None, cin_total=None, scale=N
     return PackedConv(wp.to(dtype).contiguous(), bp, sp, KH, KW, cin_total, cout_store, cout, korder=korder, wino_m=wm, wino_u=wu, wino_up=wup)
 
 
+def split3(x):
+    """float32 tensor -> three bfloat16 tensors (h, m, l) with h + m + l == x for every normal float32 (round-to-nearest splits)"""
+    x = x.float()
+    h = x.to(torch.bfloat16)
+    r = x - h.float()
+    m = r.to(torch.bfloat16)
+    l = (r - m.float()).to(torch.bfloat16)
+    return h, m, l
+
+
+def pack_conv_split3(weight, bias=None, *, scale=None):
+    """nn.Linear / 1x1 conv weight [Cout, Cin] for the split-precision GEMM (csrc/gemm_split3.hip): PackedConv with w = [3, rows, Kpad]
+    bfloat16 planes (h, m, l), K padded to 32, rows to 16; bias / scale float32 as in pack_conv."""
+    w = weight.detach().float().cpu()
+    if w.dim() == 4:
+        assert w.shape[2] == 1 and w.shape[3] == 1
+        w = w[:, :, 0, 0]
+    cout, cin = w.shape
+    assert cin % 32 == 0, "split GEMM: K must be a multiple of 32"
+    cout_store = round_up(cout, 4)
+    rows = round_up(cout_store, 16)
+    wp = torch.zeros(rows, cin)
+    wp[:cout] = w
+    planes = torch.stack(split3(wp)).contiguous()
+    bp = None
+    if bias is not None:
+        bp = torch.zeros(rows)
+        bp[:cout] = bias.detach().float().cpu()
+    sp = None
+    if scale is not None:
+        sp = torch.zeros(rows)
+        sp[:cout] = scale.detach().float().cpu()
+    return PackedConv(planes, bp, sp, 1, 1, cin, cout_store, cout)
+
+
 def pack_conv_transpose(weight, bias, *, dtype):
     """nn.ConvTranspose2d(kernel=stride=s, padding=0) (dpt.py:41-52): weight [Cin, Cout, s, s].
     out[b, y*s+dy, x*s+dx, co] = bias[co] + sum_ci x[b,y,x,ci] * weight[ci,co,dy,dx]  -> a GEMM with

@@ -12,7 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import third_party as tp
-from patchfusion_amd.packing import unpack_conv, winograd_applies
+from patchfusion_amd.packing import split3 as pk_split3, unpack_conv, winograd_applies
 
 
 def _as4(t):
@@ -116,6 +116,42 @@ class FakeOps:
         y4[..., :n] = v.to(y4.dtype)
         return y
 
+    # ---- split-precision linears: the planes are summed back to float32 (exact) and the layer evaluated in plain float32 ----
+    @staticmethod
+    def _store3(y3, v):
+        h, m, l = pk_split3(v)
+        y3[0], y3[1], y3[2] = h, m, l
+
+    @staticmethod
+    def split3(x, y3):
+        FakeOps._store3(y3, x.float())
+        return y3
+
+    @staticmethod
+    def conv_split3(x3, pw, y, act=None, res=None, res2=None):
+        x = x3.float().sum(0)
+        w = pw.w.float().sum(0)[:pw.cout, :pw.cin].to(x.device)
+        v = x[:, :pw.cin] @ w.t()
+        if pw.bias is not None:
+            v = v + pw.bias[:pw.cout].to(v.device)
+        v = _act(v, act)
+        if pw.scale is not None:
+            v = v * pw.scale[:pw.cout].to(v.device)
+        if res is not None:
+            v = v + res[:, :pw.cout].float()
+        if res2 is not None:
+            v = v + res2[:, :pw.cout].float()
+        if y.dtype == torch.bfloat16:
+            FakeOps._store3(y[:, :, :pw.cout], v)
+        else:
+            y[:, :pw.cout] = v
+        return y
+
+    @staticmethod
+    def layernorm_split3(x, y3, g, b, eps):
+        FakeOps._store3(y3, F.layer_norm(x.float(), (x.shape[-1],), g, b, eps))
+        return y3
+
     @staticmethod
     def patch_im2col(img, out):
         B, _, H, W = img.shape
@@ -147,7 +183,11 @@ class FakeOps:
         D = qkv.shape[1] // 3
         q, k, v = qkv.float().view(B, S, 3, heads, D // heads).permute(2, 0, 3, 1, 4)
         a = ((q * (D // heads) ** -0.5) @ k.transpose(-2, -1)).softmax(dim=-1)
-        out[:] = (a @ v).transpose(1, 2).reshape(B * S, D).to(out.dtype)
+        o = (a @ v).transpose(1, 2).reshape(B * S, D)
+        if qkv.dtype == torch.float32 and out.dtype == torch.bfloat16:       # split planes for the projection (ops.conv_split3)
+            FakeOps._store3(out, o)
+        else:
+            out[:] = o.to(out.dtype)
 
     @staticmethod
     def swin_ln_partition(x, xw, g, b, eps, shift):

@@ -377,6 +377,83 @@ def vit_attention_split(dt):
             os.environ["PF_ATTN_QKV"] = old
 
 
+def gemm_split3(dt):
+    """split-precision linear layer (csrc/gemm_split3.hip) against float64 on the SAME float32 operands: the three-plane split must be
+    exact (h + m + l == x bit for bit), and the GEMM's error must be float32-grade (the dropped terms are O(2^-24) of |x||w|), at a
+    ragged token count with every epilogue option, f32 output and split (three-plane) output, both tile shapes."""
+    import os
+    o = hip()
+    g = torch.Generator().manual_seed(71)
+    errs = []
+    x = (torch.randn(1037, 96, generator=g) * torch.logspace(-6, 6, 96)).to(DEV)
+    xb = torch.zeros(1037, 128, device=DEV)
+    xb[:, 8:104] = x
+    x3 = torch.zeros(3, 1037, 96, dtype=torch.bfloat16, device=DEV)
+    o.split3(xb[:, 8:104], x3)
+    exact = bool((x3.double().sum(0) == x.double()).all())
+    h, m, l = pk.split3(x.cpu())
+    same = bool((x3.cpu() == torch.stack([h, m, l])).all())
+    info = [f"split exact={exact} host-identical={same}"]
+    if not (exact and same):
+        return float("inf"), 1e-6, info[0]
+    for tile, (M, K, N, act, res, res2, scale) in enumerate([(1037, 256, 544, "gelu", True, True, True), (2 * 1037, 1024, 1024, None, True, False, False),
+                                                             (777, 1024, 3072, None, False, False, False), (1037, 4096, 1024, "relu", True, False, True)]):
+        w = torch.randn(N, K, generator=g) / K ** 0.5
+        b = torch.randn(N, generator=g)
+        sc = (0.5 + torch.rand(N, generator=g)) if scale else None
+        pw3 = pk.pack_conv_split3(w, b, scale=sc).to(DEV)
+        pw = pk.pack_conv(w.view(N, K, 1, 1), b, dtype=torch.float32, scale=sc).to(DEV)
+        x = torch.randn(M, K, generator=g).to(DEV)
+        r1 = torch.randn(M, N, generator=g).to(DEV) if res else None
+        r2 = torch.randn(M, N, generator=g).to(DEV) if res2 else None
+        ref = x.double() @ w.double().t().to(DEV) + b.double().to(DEV)
+        if act == "gelu":
+            ref = torch.nn.functional.gelu(ref)
+        elif act == "relu":
+            ref = torch.relu(ref)
+        if sc is not None:
+            ref = ref * sc.double().to(DEV)
+        if r1 is not None:
+            ref = ref + r1.double()
+        if r2 is not None:
+            ref = ref + r2.double()
+        den = max(1.0, float(ref.abs().max()))
+        x3 = torch.empty(3, M, K, dtype=torch.bfloat16, device=DEV)
+        o.split3(x, x3)
+        for force in ("64", "128"):
+            os.environ["PF_S3_TILE_NOW"] = force
+            y = torch.zeros(M, N, device=DEV)
+            o.conv_split3(x3, pw3, y, act=act, res=r1, res2=r2)
+            y3 = torch.zeros(3, M, N, dtype=torch.bfloat16, device=DEV)
+            o.conv_split3(x3, pw3, y3, act=act, res=r1, res2=r2)
+            e1 = float((y.double() - ref).abs().max()) / den
+            e3 = float((y3.double().sum(0) - ref).abs().max()) / den
+            errs += [e1, e3]
+        os.environ.pop("PF_S3_TILE_NOW", None)
+        yf = torch.zeros(1, 1, M, N, device=DEV)
+        o.conv(x.view(1, 1, M, K), pw, yf, act=act, res=r1.view(1, 1, M, N) if res else None, res2=r2.view(1, 1, M, N) if res2 else None)
+        ef = float((yf.view(M, N).double() - ref).abs().max()) / den
+        info.append(f"K={K} N={N}: split {e1:.2e} (planes out {e3:.2e}) vs f32 kernel {ef:.2e}")
+    # the fused producers: LayerNorm and attention outputs written as planes == the host split of their float32 outputs, bit for bit
+    xs = torch.randn(2 * 1037, 1024, generator=g).to(DEV) * 3 + 0.5
+    gam, bet = torch.randn(1024, generator=g).to(DEV), torch.randn(1024, generator=g).to(DEV)
+    yf = torch.empty_like(xs)
+    o.layernorm(xs, yf, gam, bet, 1e-6)
+    y3 = torch.zeros(3, 2 * 1037, 1024, dtype=torch.bfloat16, device=DEV)
+    o.layernorm_split3(xs, y3, gam, bet, 1e-6)
+    ln_same = bool((y3.cpu() == torch.stack(pk.split3(yf.cpu()))).all())
+    qkv = torch.randn(2 * 1037, 3 * 1024, generator=g).to(DEV)
+    af = torch.empty(2 * 1037, 1024, device=DEV)
+    o.vit_attention(qkv, af, 2, 1037, 16)
+    a3 = torch.zeros(3, 2 * 1037, 1024, dtype=torch.bfloat16, device=DEV)
+    o.vit_attention(qkv, a3, 2, 1037, 16)
+    at_same = bool((a3.cpu() == torch.stack(pk.split3(af.cpu()))).all())
+    info.append(f"layernorm planes identical={ln_same} attention planes identical={at_same}")
+    if not (ln_same and at_same):
+        return float("inf"), 2e-6, "; ".join(info)
+    return max(errs), 2e-6, "; ".join(info)
+
+
 def swin_ops(dt):
     errs = []
     for (B, H, W, C, heads) in ((1, 14, 19, 64, 32), (1, 28, 37, 64, 16), (2, 30, 25, 32, 8), (1, 13, 24, 256, 8), (1, 12, 12, 128, 8), (1, 17, 12, 256, 16), (1, 12, 24, 64, 8)):
@@ -574,8 +651,8 @@ CHECKS = {
     "conv_split_n272_res_views": conv_split_n272_res_views, "conv_split_gemm_n544_inplace": conv_split_gemm_n544_inplace,
     "conv_gemm_vitl_linear_shape": conv_gemm_vitl_linear_shape, "conv_dominant_launch": conv_dominant_launch,
     "conv_transpose": conv_transpose, "patch_embed_tokens": patch_embed_tokens, "layernorm": layernorm,
-    "vit_attention": vit_attention, "vit_attention_split": vit_attention_split, "swin_ops": swin_ops, "resize_ops": resize_ops, "roi_ops": roi_ops,
+    "vit_attention": vit_attention, "vit_attention_split": vit_attention_split, "gemm_split3": gemm_split3, "swin_ops": swin_ops, "resize_ops": resize_ops, "roi_ops": roi_ops,
     "conv_winograd": conv_winograd, "conv_winograd_fused": conv_winograd_fused, "misc_ops": misc_ops, "bins_ops": bins_ops, "stitch_ops": stitch_ops,
 }
-F32_ONLY = {"bins_ops", "stitch_ops", "conv_winograd", "conv_winograd_fused", "vit_attention_split"}
+F32_ONLY = {"bins_ops", "stitch_ops", "conv_winograd", "conv_winograd_fused", "vit_attention_split", "gemm_split3"}
 DTYPES = {"fp32": torch.float32, "bf16": torch.bfloat16}

@@ -67,11 +67,16 @@ def work(name, a, k):
         opix = y4.shape[0] * (y4.shape[1] // s) * (y4.shape[2] // s)
         fl = 2.0 * opix * pw.cin * pw.KH * pw.KW * pw.cout
         wino = winograd_applies(pw, x4.shape[0] * x4.shape[1] * x4.shape[2], k.get("stride", 1), k.get("pad", 0), k.get("act"))
-        return "flop", fl, f"{tuple(x4.shape[:3])} {pw.cin}->{pw.cout} k{pw.KH} s{k.get('stride', 1)}" + (" convT" if s > 1 else "") + \
-            (f" [winograd F{pw.wino_m}: 3 steps, rate = direct-conv FLOPs / time]" if wino else "")
+        from patchfusion_amd import hip_ops
+        fused = wino and pw.wino_up is not None and hip_ops._fused_wanted(x4.shape[0], x4.shape[1], x4.shape[2], pw.cin, pw.cout)
+        tag = ""
+        if wino:
+            tag = (f" [winograd F{pw.wino_m} FUSED kernel, rate = direct-conv FLOPs / time]" if fused else
+                   f" [winograd F{pw.wino_m}: 3 steps, rate = direct-conv FLOPs / time]")
+        return "flop", fl, f"{tuple(x4.shape[:3])} {pw.cin}->{pw.cout} k{pw.KH} s{k.get('stride', 1)}" + (" convT" if s > 1 else "") + tag
     if name == "vit_attention":
         qkv, out, B, S, heads = a[:5]
-        return "flop", 4.0 * B * heads * S * S * 64, f"B{B} S{S} heads{heads} (incl. qkv_split)"
+        return "flop", 4.0 * B * heads * S * S * 64, f"B{B} S{S} heads{heads}" + (" (reads the QKV rows, no split)" if qkv.dtype == torch.float32 else " (incl. qkv_split)")
     if name == "swin_window_attention":
         qkv, out = a[0], a[1]
         return "byte", nbytes(qkv) + nbytes(out), f"tokens {qkv.shape[0]} C{out.shape[1]} heads{a[7]}"
@@ -218,7 +223,7 @@ def main():
     out = [f"# every kernel launch of one 4K image pass (ViT-L, P=16, process_num=8, {dtype}), each distinct call timed standalone", "",
            f"sum of standalone times: {tot:.1f} ms per image; {sum(r['launches'] for r in rows)} launches, {len(rows)} distinct (op, shape) calls.",
            f"MFMA-bound rows: TFLOP/s vs {MFMA_PEAK[dtype] / 1e12:.1f} TF/s dense peak; HBM-bound rows: algorithmic GB/s vs 8000 GB/s.",
-           "Rows tagged [winograd Fm] run the three-step float32 Winograd layer (csrc/winograd.hip): their rate is the DIRECT convolution's "
+           "Rows tagged [winograd Fm ...] run the float32 Winograd layer (fused kernel csrc/wino_fused.hip, or the three steps of csrc/winograd.hip): their rate is the DIRECT convolution's "
            "FLOPs over the layer time, so it can exceed the MFMA peak (the layer multiplies (m+2)^2 / (9 m^2) as often).", "",
            "## per op", "", "| op | bound | total ms / image | share |", "|---|---|---:|---:|"]
     for (op, kind), t in sorted(by_op.items(), key=lambda kv: -kv[1]):

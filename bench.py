@@ -150,7 +150,7 @@ def main():
         "config": {"workload": f"Depth-Anything-{args.encoder}14 PatchFusion, 2160x3840 synthetic RGB, "
                                f"{split[0]}x{split[1]} regular tiling (cai_mode m1, {P} tiles), process_num={args.process_num}, "
                                f"random-init weights ({which})",
-                   "precision": "float32 storage + f32 MFMA (exact mode = the reference's precision)" if args.dtype == "fp32"
+                   "precision": PRECISION_F32[split3_on()] if args.dtype == "fp32"
                                 else "bf16 storage + bf16 MFMA, f32 accumulation, f32 metric-bins head",
                    "parallelism": f"patch-sharded x{N}, coarse+G2L replicated, RCCL all_gather of tile depths" if N > 1 else "single GPU"},
     }
@@ -158,6 +158,20 @@ def main():
     if rank == 0 and not args.no_roofline:
         out["roofline"] = roofline(args.dtype, dev)
         log(f"roofline: {out['roofline']}")
+    if N == 1 and args.dtype == "fp32" and not args.no_secondary and split3_on():
+        # the same pass with every GEMM on the float32 MFMA (PF_LINEAR_SPLIT3=0): the number to quote if split-precision linears are not
+        # accepted as "float32", and the measured distance between the two float32 evaluations
+        os.environ["PF_LINEAR_SPLIT3"] = "0"
+        try:
+            dt3, depth3 = run_mode("fp32")
+        finally:
+            os.environ.pop("PF_LINEAR_SPLIT3", None)
+        d3 = (depth3 - depth).abs()
+        out["f32_mfma_only"] = {"value": round(P * args.steps / dt3, 3), "unit": "patches/s", "ms_per_step": round(dt3 / args.steps * 1e3, 3),
+                                "precision": PRECISION_F32[False],
+                                "max_abs_depth_diff_vs_headline": float(d3.max()), "mean_abs_depth_diff_vs_headline": float(d3.mean())}
+        log(f"f32 MFMA only: {out['f32_mfma_only']}")
+        del depth3
     if N == 1 and args.dtype == "fp32" and not args.no_secondary:
         dt2, depth2 = run_mode("bf16")
         diff = (depth2 - depth).abs().flatten()
@@ -177,6 +191,18 @@ def main():
     if world > 1:
         barrier()                      # the other ranks wait for rank 0's roofline launch, then all leave together
         torch.distributed.destroy_process_group()
+
+
+PRECISION_F32 = {
+    True: "float32 storage; convolutions and attention on the f32 MFMA; the ViT block linears as split-precision GEMMs (each f32 operand "
+          "= three bf16 planes, six partial products on the bf16 MFMA, f32 accumulation: error vs float64 <= the f32 MFMA kernel's, "
+          "tests/op_checks.py gemm_split3; PF_LINEAR_SPLIT3=0 -> f32_mfma_only)",
+    False: "float32 storage + f32 MFMA everywhere (exact mode = the reference's precision)"}
+
+
+def split3_on():
+    from patchfusion_amd.engine import linear_split3_enabled
+    return linear_split3_enabled()
 
 
 def gemm_sweep(dtype, dev, only=()):

@@ -91,7 +91,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split3_kernel(const pf_conv
     inc[i] = src == zero ? 0 : 64;
   }
   const unsigned smem_base = lds_addr(smem);
+#ifdef PF_S3_DBG           // timing decomposition (results wrong by construction): env PF_S3_DBG bit 0 = no DMA after the first ring fill,
+  const int dbg = p.pad;   // bit 1 = no MFMA, bit 2 = no fragment reads after the first
+#define S3_DBG(bit) (dbg & (bit))
+#else
+#define S3_DBG(bit) 0
+#endif
+  int issued = 0;
   auto issue = [&](int stage) {
+    if (S3_DBG(1) && issued >= NS) return;
+    ++issued;
     const unsigned dst = smem_base + stage * STAGE + wave * (PPW * 1024);
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
@@ -129,6 +138,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split3_kernel(const pf_conv
   const int nk = p.Cin / 32;
   struct Frags { uint4 w[3][FN], x[3][FM]; };
   auto read_frags = [&](Frags& f, int kc) {
+    if (S3_DBG(4) && kc > 1) return;
     const char* S = smem + (kc % NS) * STAGE;
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
@@ -140,6 +150,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split3_kernel(const pf_conv
   };
   // six partial products, smallest first; within a term the FN*FM accumulators are independent chains
   auto multiply = [&](const Frags& f) {
+    if (S3_DBG(2)) return;
 #define S3_TERM(PW, PX)                                                                                                      \
   _Pragma("unroll") for (int fn = 0; fn < FN; ++fn) _Pragma("unroll") for (int fm = 0; fm < FM; ++fm)                       \
       acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.w[PW][fn]), __builtin_bit_cast(bf16x8, f.x[PX][fm]), \
@@ -245,7 +256,14 @@ int launch(const pf_conv_params& p, hipStream_t st) {
 extern "C" int pf_gemm_split3(const pf_conv_params* p, void* stream) {
   const char* e = nullptr;
   if (!p || !p->x || !p->w || !p->y) return PF_ERR_ARG;
+#ifdef PF_S3_DBG
+  pf_conv_params pd = *p;
+  if (const char* s = getenv("PF_S3_DBG")) pd.pad = atoi(s);
+  p = &pd;
+  if (p->KH != 1 || p->KW != 1 || p->stride != 1 || p->shuffle > 1) e = "1x1 / linear layers only";
+#else
   if (p->KH != 1 || p->KW != 1 || p->stride != 1 || p->pad != 0 || p->shuffle > 1) e = "1x1 / linear layers only";
+#endif
   else if (p->Cin <= 0 || p->Cin % 32 || p->Kpad < p->Cin || p->Kpad % 32 || p->x_ld % 8 || p->x_ld < p->Cin) e = "K must be a multiple of 32, x_ld of 8";
   else if (p->Cout <= 0 || p->Cout % 4 || p->y_ld % 4 || p->w_rows < p->Cout) e = "Cout / y_ld must be multiples of 4";
   else if ((p->res && p->res_ld % 4) || (p->res2 && p->res2_ld % 4)) e = "residual ld must be a multiple of 4";

@@ -158,6 +158,7 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
         self._side_stream = None
         self._aux_streams = []
         self.n_streams = int(_os.environ.get("PF_STREAMS", config.get("n_streams", 2)))
+        self.split_single_batch = _os.environ.get("PF_SPLIT_SINGLE_BATCH", "1") != "0"
         # ViT encoder of the fine branch over ALL tiles of this rank in one launch per layer (M = tiles x 1037 token rows) instead of
         # once per process_num batch; the DPT head / fusion keep the process_num batches.  Identical numbers (no op mixes rows).
         # Off by default: measured 290.2 vs 287.0 ms per image (round 3, gpurun_out/r3a_bench_*.json) -- with two streams the tails of
@@ -393,6 +394,10 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
         nets = self._engine
         # consecutive batches alternate between the current stream and an auxiliary stream: the low-occupancy
         # kernels of one batch (coarse pyramid levels L0..L2, B x 14x19 ... 56x74 maps) fill the gaps of the other
+        # A shard that fits ONE process_num batch (the multi-GPU case: P/N <= process_num tiles per rank) is cut in two half batches so the
+        # same overlap applies (identical numbers: no op mixes rows of a batch).  PF_SPLIT_SINGLE_BATCH=0 keeps the single batch.
+        if (img.is_cuda and self.overlap_batches and self.split_single_batch and 4 <= (hi - lo) <= process_num):
+            process_num = (hi - lo + 1) // 2
         use_aux = img.is_cuda and self.overlap_batches and (hi - lo) > process_num
         main = torch.cuda.current_stream() if img.is_cuda else None
         streams = [main]

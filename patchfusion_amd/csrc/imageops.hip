@@ -19,6 +19,7 @@ struct Lerp {
   float l0, l1;
 };
 __device__ __forceinline__ Lerp ac_coord(int dst, float scale, int in) {
+#pragma clang fp contract(off)      // l1 = fl(scale * dst) - i0 like the reference's CPU evaluation; a fused multiply-subtract would differ by an ulp
   const float src = scale * dst;
   Lerp r;
   r.i0 = (int)src;
@@ -26,6 +27,11 @@ __device__ __forceinline__ Lerp ac_coord(int dst, float scale, int in) {
   r.l1 = src - r.i0;
   r.l0 = 1.0f - r.l1;
   return r;
+}
+// the bilinear blend, one evaluation order for every resize kernel (no contraction: the kernels agree bit for bit)
+__device__ __forceinline__ float bilerp(const Lerp& ly, const Lerp& lx, float v00, float v01, float v10, float v11) {
+#pragma clang fp contract(off)
+  return ly.l0 * (lx.l0 * v00 + lx.l1 * v01) + ly.l1 * (lx.l0 * v10 + lx.l1 * v11);
 }
 inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 
@@ -63,7 +69,7 @@ __global__ void resize_bilinear_kernel(const void* __restrict__ x, int x_ld, int
     ld8x<T>(x, (r1 + lx.i0) * x_ld + v * 8, in_f32, v10);
     ld8x<T>(x, (r1 + lx.i1) * x_ld + v * 8, in_f32, v11);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = ly.l0 * (lx.l0 * v00[e] + lx.l1 * v01[e]) + ly.l1 * (lx.l0 * v10[e] + lx.l1 * v11[e]);
+    for (int e = 0; e < 8; ++e) o[e] = bilerp(ly, lx, v00[e], v01[e], v10[e], v11[e]);
     const long pix = orow + ox;
     if (add) {
       float a[8];
@@ -109,11 +115,127 @@ __global__ void resize_concat_kernel(ResizeSrc s0, ResizeSrc s1, ResizeSrc s2, i
         ld8x<T>(s.x, (r1 + lx.i0) * s.ld + v * 8, 0, v10);
         ld8x<T>(s.x, (r1 + lx.i1) * s.ld + v * 8, 0, v11);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = ly.l0 * (lx.l0 * v00[e] + lx.l1 * v01[e]) + ly.l1 * (lx.l0 * v10[e] + lx.l1 * v11[e]);
+        for (int e = 0; e < 8; ++e) o[e] = bilerp(ly, lx, v00[e], v01[e], v10[e], v11[e]);
         st8x<T>(y, (orow + ox) * y_ld + coff + v * 8, 0, o);
       }
       coff += s.C;
     }
+  }
+}
+
+// ---- source-aligned bilinear resize (version 2) -------------------------------------------------------------------------------------
+// The kernels above walk the OUTPUT pixels and fetch four taps each: an upsampling (every use in the image pass: x1.75 / x2) re-fetches
+// every source pixel ~(scale)^2 x 4 times and sits at 31-40 % of the HBM roofline, bound by load issue, not bytes (profiles/r3_op_roofline).
+// Here a block owns one SOURCE row interval (b, r) and a thread one source column interval c for one 16-byte channel vector: the four taps
+// x[r..r+1][c..c+1] are loaded ONCE and every output pixel whose (i0y, i0x) == (r, c) is produced from them -- ~1.3 loads per output
+// instead of 4, no per-output index division.  The outputs of an interval are found with the SAME float expression the output-walking
+// kernels use ((int)(scale * o)), so every output pixel is written exactly once with bit-identical taps, weights and evaluation order
+// (any scale, down-sampling included: intervals without outputs simply write nothing).
+__device__ __forceinline__ int first_dst(int c, float scale, int out) {      // smallest o in [0, out] with (int)(scale * o) >= c
+  if (c <= 0) return 0;
+  if (scale <= 0.f) return out;
+  int o = (int)((float)c / scale);
+  o = o < 0 ? 0 : (o > out ? out : o);
+  while (o > 0 && (int)(scale * (o - 1)) >= c) --o;
+  while (o < out && (int)(scale * o) < c) ++o;
+  return o;
+}
+
+template <typename T>
+__device__ __forceinline__ void ldv(const T* p, float (&v)[16 / sizeof(T)]) {
+  if constexpr (sizeof(T) == 4) load4(p, v);
+  else load8(p, v);
+}
+template <typename T>
+__device__ __forceinline__ void stv(T* p, const float (&v)[16 / sizeof(T)]) {
+  if constexpr (sizeof(T) == 4) store4(p, v[0], v[1], v[2], v[3]);
+  else store8(p, v);
+}
+
+// Block: RPB consecutive source rows (b, r .. r + RPB - 1) of every source.  Per source the block first tabulates, in LDS, the output-column
+// range of every source column interval and the horizontal weights of every output column (they depend on neither b, r nor the channel).
+// A thread then owns a (column interval, channel vector) and walks DOWN its rows: the bottom taps of one row are the top taps of the next, so
+// a row costs two 16-byte loads (2.25 per row with the first), and per output pixel one LDS read, the blend and one 16-byte store.
+constexpr int RESIZE_RPB = 8;
+template <typename T>
+__global__ void resize_src_kernel(ResizeSrc s0, ResizeSrc s1, ResizeSrc s2, int nsrc, int B, int Hmax, void* __restrict__ yv, int y_ld, int OH,
+                                  int OW, const void* __restrict__ addv, int add_ld, int Wmax, int rpb) {
+  constexpr int N = 16 / sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) char resize_lds[];
+  int2* rowrange = reinterpret_cast<int2*>(resize_lds);                                  // [RESIZE_RPB] output rows [x, y) of source row r
+  int2* colrange = reinterpret_cast<int2*>(resize_lds + RESIZE_RPB * 8);                 // [Wmax]  output columns [x, y) of column interval c
+  float2* wx = reinterpret_cast<float2*>(resize_lds + RESIZE_RPB * 8 + (size_t)Wmax * 8);  // [OW]    (l0, l1) of output column ox
+  T* __restrict__ y = reinterpret_cast<T*>(yv);
+  const T* __restrict__ add = reinterpret_cast<const T*>(addv);
+  const int tid = threadIdx.x, nthr = blockDim.x * gridDim.x, gtid = blockIdx.x * blockDim.x + tid;
+  const int gpi = (Hmax + rpb - 1) / rpb;                                                  // row groups per image
+  int coff = 0;
+  for (int si = 0; si < nsrc; ++si) {
+    const ResizeSrc& s = si == 0 ? s0 : (si == 1 ? s1 : s2);
+    __syncthreads();
+    for (int c = tid; c < s.W; c += blockDim.x) colrange[c] = make_int2(first_dst(c, s.sw, OW), first_dst(c + 1, s.sw, OW));
+    for (int ox = tid; ox < OW; ox += blockDim.x) {
+      const Lerp lx = ac_coord(ox, s.sw, s.W);
+      wx[ox] = make_float2(lx.l0, lx.l1);
+    }
+    const T* __restrict__ x = reinterpret_cast<const T*>(s.x);
+    const int cv = s.C / N, n = s.W * cv;
+    const float inv_cv = 1.0f / (float)cv;
+    for (int g = blockIdx.y; g < B * gpi; g += gridDim.y) {              // block-uniform
+      const int b = g / gpi, rbeg = (g - b * gpi) * rpb;
+      const int rend = rbeg + rpb < s.H ? rbeg + rpb : s.H;
+      __syncthreads();                                                  // (also publishes the column tables on the first pass)
+      if (tid < rpb) rowrange[tid] = make_int2(first_dst(rbeg + tid, s.sh, OH), first_dst(rbeg + tid + 1, s.sh, OH));
+      __syncthreads();
+      if (rbeg >= rend) continue;
+      for (int i = gtid; i < n; i += nthr) {
+        int c = (int)(((float)i + 0.5f) * inv_cv);                       // i / cv for i < 2^22 (the host checks)
+        int v = i - c * cv;
+        if (v < 0) { --c; v += cv; } else if (v >= cv) { ++c; v -= cv; }
+        const int2 rg = colrange[c];
+        if (rg.x >= rg.y) continue;
+        const long o0 = (long)c * s.ld + v * N, o1 = (long)(c + (c < s.W - 1 ? 1 : 0)) * s.ld + v * N;
+        const T* __restrict__ rowp = x + ((long)b * s.H + rbeg) * s.W * s.ld;
+        float v00[N], v01[N], v10[N], v11[N];
+        ldv<T>(rowp + o0, v00);
+        ldv<T>(rowp + o1, v01);
+        for (int r = rbeg; r < rend; ++r) {
+          if (r < s.H - 1) {
+            rowp += (long)s.W * s.ld;
+            ldv<T>(rowp + o0, v10);
+            ldv<T>(rowp + o1, v11);
+          } else {
+#pragma unroll
+            for (int e = 0; e < N; ++e) { v10[e] = v00[e]; v11[e] = v01[e]; }
+          }
+          const int2 rr = rowrange[r - rbeg];
+          for (int oy = rr.x; oy < rr.y; ++oy) {
+            const Lerp ly = ac_coord(oy, s.sh, s.H);
+            const long pix0 = ((long)b * OH + oy) * OW;
+            T* __restrict__ yp = y + (pix0 + rg.x) * y_ld + coff + v * N;
+            for (int ox = rg.x; ox < rg.y; ++ox, yp += y_ld) {
+              const float2 w = wx[ox];
+              Lerp lx;
+              lx.l0 = w.x;
+              lx.l1 = w.y;
+              float o[N];
+#pragma unroll
+              for (int e = 0; e < N; ++e) o[e] = bilerp(ly, lx, v00[e], v01[e], v10[e], v11[e]);
+              if (add) {
+                float a[N];
+                ldv<T>(add + (pix0 + ox) * add_ld + v * N, a);
+#pragma unroll
+                for (int e = 0; e < N; ++e) o[e] = a[e] + o[e];
+              }
+              stv<T>(yp, o);
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < N; ++e) { v00[e] = v10[e]; v01[e] = v11[e]; }
+        }
+      }
+    }
+    coff += s.C;
   }
 }
 
@@ -509,9 +631,48 @@ __global__ void resize_bilinear_f32_kernel(const float* __restrict__ x, int H, i
     else hipLaunchKernelGGL(kern<float>, g, dim3(256), 0, ST(stream), __VA_ARGS__);                                     \
   } while (0)
 
+// PF_RESIZE_V2=0: the output-walking kernels (A/B measurements)
+static bool resize_v2() {
+  const char* e = getenv("PF_RESIZE_V2");      // read per call: the parity test flips it between two launches
+  return !(e && e[0] == '0');
+}
+
+// grid of the source-aligned kernels: x = up to 4 blocks per source row, y = groups of rpb consecutive source rows of one image;
+// LDS = row ranges [8] + column ranges [Wmax] + weights [OW]
+template <typename T>
+static int launch_resize_src(const ResizeSrc* s, int nsrc, int B, void* y, int y_ld, int OH, int OW, const void* add, int add_ld, hipStream_t st) {
+  constexpr int N = 16 / sizeof(T);
+  int Hmax = 0, Wmax = 0;
+  long items = 0;
+  for (int i = 0; i < nsrc; ++i) {
+    Hmax = s[i].H > Hmax ? s[i].H : Hmax;
+    Wmax = s[i].W > Wmax ? s[i].W : Wmax;
+    const long it = (long)s[i].W * (s[i].C / N);
+    items = it > items ? it : items;
+  }
+  const size_t lds = RESIZE_RPB * 8 + (size_t)Wmax * 8 + (size_t)OW * 8;
+  if (items >= (1L << 22) || lds > 60000) return PF_ERR_ARG;
+  // rows per block: 8 when that still leaves >= 4 blocks per CU, fewer for small maps
+  const long gx = (items + 255) / 256 > 4 ? 4 : (items + 255) / 256;
+  int rpb = RESIZE_RPB;
+  while (rpb > 1 && (long)B * ((Hmax + rpb - 1) / rpb) * gx < 1024) rpb >>= 1;
+  long gy = (long)B * ((Hmax + rpb - 1) / rpb);
+  gy = gy > 65535 ? 65535 : gy;
+  const ResizeSrc none{};
+  hipLaunchKernelGGL(resize_src_kernel<T>, dim3((unsigned)gx, (unsigned)gy), dim3(256), lds, st, s[0], nsrc > 1 ? s[1] : none, nsrc > 2 ? s[2] : none,
+                     nsrc, B, Hmax, y, y_ld, OH, OW, add, add_ld, Wmax, rpb);
+  return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_LAUNCH;
+}
+
 extern "C" int pf_resize_bilinear(const void* x, int x_ld, int B, int H, int W, int C, void* y, int y_ld, int OH, int OW,
                                   const void* add, int add_ld, int in_f32, int out_f32, int dtype, void* stream) {
   if (!x || !y || C % 8 || x_ld % 8 || y_ld % 8 || (add && add_ld % 8)) return PF_ERR_ARG;
+  const bool homogeneous = dtype == PF_DTYPE_BF16 ? (!in_f32 && !out_f32) : true;      // (dtype f32: everything is float32)
+  if (homogeneous && resize_v2()) {
+    const ResizeSrc s0{x, x_ld, H, W, C, ac_scale(H, OH), ac_scale(W, OW)};
+    return dtype == PF_DTYPE_BF16 ? launch_resize_src<bf16_t>(&s0, 1, B, y, y_ld, OH, OW, add, add_ld, ST(stream))
+                                  : launch_resize_src<float>(&s0, 1, B, y, y_ld, OH, OW, add, add_ld, ST(stream));
+  }
   LAUNCH_ROWS(resize_bilinear_kernel, B * OH, OW * (C / 8), x, x_ld, B, H, W, C, y, y_ld, OH, OW, add, add_ld, in_f32, out_f32,
               ac_scale(H, OH), ac_scale(W, OW));
   return ok();
@@ -530,6 +691,9 @@ extern "C" int pf_resize_concat(const void* const* xs, const int* lds, const int
   int cvmax = 0;
   for (int i = 0; i < nsrc; ++i) cvmax = Cs[i] / 8 > cvmax ? Cs[i] / 8 : cvmax;
   (void)cv;
+  if (resize_v2())
+    return dtype == PF_DTYPE_BF16 ? launch_resize_src<bf16_t>(s, nsrc, B, y, y_ld, OH, OW, nullptr, 0, ST(stream))
+                                  : launch_resize_src<float>(s, nsrc, B, y, y_ld, OH, OW, nullptr, 0, ST(stream));
   LAUNCH_ROWS(resize_concat_kernel, B * OH, OW * cvmax, s[0], s[1], s[2], nsrc, B, y, y_ld, OH, OW);
   return ok();
 }

@@ -495,6 +495,28 @@ def resize_ops(dt):
             o.resize(x, y2, add=add)
             res.append((buf, y2))
         errs += [_err(a, c) for a, c in zip(res[0], res[1])]
+    # the source-aligned kernels (version 2, default) against the output-walking ones (PF_RESIZE_V2=0): every output pixel written exactly
+    # once, bit-identical -- up-sampling, down-sampling, identity, a single output row / column
+    import os
+    same = True
+    for (h, w, oh, ow, C) in ((14, 19, 28, 37, 64), (224, 296, 392, 518, 8), (56, 74, 28, 37, 32), (37, 50, 9, 200, 16), (8, 11, 8, 11, 64),
+                              (5, 7, 1, 1, 8), (1, 1, 6, 9, 8), (30, 3, 31, 2, 24)):
+        x = _rand((2, h, w, C), dt, h + 100)
+        add = _rand((2, oh, ow, C), dt, w + 100)
+        outs = []
+        for v2 in ("1", "0"):
+            os.environ["PF_RESIZE_V2"] = v2
+            y1 = torch.full((2, oh, ow, C + 16), -7.0, dtype=dt, device=DEV)
+            hip().resize(x, y1[..., 8:8 + C])
+            y2 = torch.full((2, oh, ow, C), -7.0, dtype=dt, device=DEV)
+            hip().resize(x, y2, add=add)
+            y3 = torch.full((2, oh, ow, 3 * C), -7.0, dtype=dt, device=DEV)
+            hip().resize_concat([x, add, x], y3)
+            outs.append((y1, y2, y3))
+        os.environ.pop("PF_RESIZE_V2", None)
+        same = same and all(bool((a == b).all()) for a, b in zip(*outs))
+    if not same:
+        return float("inf"), _tol(dt, 1e-4, 1e-2), "resize version 2 differs from the output-walking kernels"
     # the Upv1 concat buffer in one launch: 3 sources of different sizes / 2 sources into a channel slice of a wider buffer
     e0, t0, g0 = _rand((2, 49, 64, 64), dt, 31), _rand((2, 28, 37, 128), dt, 32), _rand((2, 28, 37, 128), dt, 33)
     res = []

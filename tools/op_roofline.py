@@ -74,9 +74,19 @@ def work(name, a, k):
             tag = (f" [winograd F{pw.wino_m} FUSED kernel, rate = direct-conv FLOPs / time]" if fused else
                    f" [winograd F{pw.wino_m}: 3 steps, rate = direct-conv FLOPs / time]")
         return "flop", fl, f"{tuple(x4.shape[:3])} {pw.cin}->{pw.cout} k{pw.KH} s{k.get('stride', 1)}" + (" convT" if s > 1 else "") + tag
+    if name == "conv_split3":
+        x3, pw, y = a[0], a[1], a[2]
+        fl = 2.0 * x3.shape[1] * pw.cin * pw.cout
+        return "flop", fl, (f"(1, 1, {x3.shape[1]}) {pw.cin}->{pw.cout} k1 s1 [split-precision bf16x3: USEFUL f32 FLOPs / time vs the f32 MFMA peak; 6x bf16 FLOPs executed]" + (" -> planes" if y.dtype == torch.bfloat16 else ""))
+    if name == "layernorm_split3":
+        x, y3 = a[0], a[1]
+        return "byte", nbytes(x) + nbytes(y3), f"rows {x.shape[0]} D{x.shape[1]} -> three bf16 planes"
+    if name == "split3":
+        return "byte", nbytes(a[0]) + nbytes(a[1]), f"{tuple(a[0].shape)} -> three bf16 planes"
     if name == "vit_attention":
         qkv, out, B, S, heads = a[:5]
-        return "flop", 4.0 * B * heads * S * S * 64, f"B{B} S{S} heads{heads}" + (" (reads the QKV rows, no split)" if qkv.dtype == torch.float32 else " (incl. qkv_split)")
+        return "flop", 4.0 * B * heads * S * S * 64, f"B{B} S{S} heads{heads}" + (" (reads the QKV rows, no split)" if qkv.dtype == torch.float32 else " (incl. qkv_split)") + \
+            (" -> planes" if qkv.dtype == torch.float32 and out.dtype == torch.bfloat16 else "")
     if name == "swin_window_attention":
         qkv, out = a[0], a[1]
         return "byte", nbytes(qkv) + nbytes(out), f"tokens {qkv.shape[0]} C{out.shape[1]} heads{a[7]}"

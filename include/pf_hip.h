@@ -194,6 +194,14 @@ int pf_bounded_bin_centers(const float* b, float* out, long npix, int n_bins, fl
  * pt [B,h,w,4] float = softplus(mlp) ; centers [B,hc,wc,n_bins] float ; depth [B,h,w] float */
 int pf_logbinom_depth(const float* pt, int pt_ld, const float* centers, int hc, int wc, float* depth, int B, int h,
                       int w, int n_bins, float min_temp, float max_temp, void* stream);
+/* The whole full-resolution tail of a metric-bins head in one launch (float32): cat[last(32), up(b_embedding)(128), rel?] -> Conv1x1(80) +
+ * GELU -> Conv1x1(4) + Softplus -> log-binomial expectation over the up-sampled bin centres (zoedepth_v1.py:207-219, dist_layers.py:97-121).
+ * clb: the CLB buffer [B,H,W,clb_ld] whose channels [0,32) hold `last` and (nq == 11) [rel_off, rel_off+8) the relative depth; emb: the
+ * low-resolution embedding [B,he,we,128]; w0f / b0 / w2 / b2: packing.bins_tail_weights; centers [B,hc,wc,64]; depth [B,H,W].
+ * Replaces pf_resize_bilinear (embedding into the CLB buffer) + two pf_conv + pf_logbinom_depth. */
+int pf_bins_tail(const float* clb, int clb_ld, int rel_off, const float* emb, int he, int we, const float* w0f, const float* b0,
+                 const float* w2, const float* b2, const float* centers, int hc, int wc, float* depth, int B, int H, int W, int nq,
+                 float min_temp, float max_temp, void* stream);
 
 /* ---- stitching (estimator/models/utils.py:21-36, baseline_pretrain.py:310-329,205-216) ------------ */
 /* init pass: pred[y0+i,x0+j] = depth*mask ; count[...] = mask  (P tiles) */

@@ -66,6 +66,7 @@ SIGNATURES = {
     "pf_seed_bin_centers": [vp, ci, vp, cl, ci, cf, cf, ci, ci, vp],
     "pf_bounded_bin_centers": [vp, vp, cl, ci, cf, cf, vp],
     "pf_logbinom_depth": [vp, ci, vp, ci, ci, vp, ci, ci, ci, ci, cf, cf, vp],
+    "pf_bins_tail": [vp, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, ci, ci, vp, ci, ci, ci, ci, cf, cf, vp],
     "pf_stitch_init": [vp, vp, ci, ci, vp, vp, vp, ci, ci, ci, vp],
     "pf_stitch_finish_init": [vp, vp, vp, cl, vp],
     "pf_stitch_update": [vp, vp, ci, ci, vp, ci, ci, vp, ci, ci, ci, ci, vp],

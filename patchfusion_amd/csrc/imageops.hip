@@ -2,6 +2,7 @@
 // per-tile crop+resize, roi_align, max-pool, channel-slice copy, fusion-net input packing, layout
 // conversion, the metric-bins head tail (attractor, log-binomial expectation) and the tile stitcher.
 // All loads/stores are 16-byte vectors over the contiguous channel axis of NHWC tensors.
+#include <atomic>
 #include "pf_common.h"
 #include "../../include/pf_hip.h"
 
@@ -509,6 +510,14 @@ __global__ void logbinom_depth_kernel(const float* __restrict__ pt, int pt_ld, c
   const float eps = 1e-7f;
   const float n_ = (float)(n_bins - 1) + eps;
   const float nlogn = n_ * logf(n_);
+  // log C(n, k) (Stirling form, dist_layers.py:29-45) depends on k only: tabulated once per block instead of three logf per bin, pass and
+  // pixel (the kernel was bound by those: 7 % of the HBM roofline); same expression -> same values
+  __shared__ float logc_tab[256];
+  for (int k = threadIdx.x; k < n_bins; k += blockDim.x) {
+    const float k_ = (float)k + eps;
+    logc_tab[k] = nlogn - k_ * logf(k_) - (n_ - k_) * logf(n_ - k_ + eps);
+  }
+  __syncthreads();
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int ox = (int)(i % w);
     const int oy = (int)((i / w) % h);
@@ -524,9 +533,7 @@ __global__ void logbinom_depth_kernel(const float* __restrict__ pt, int pt_ld, c
     // pass 1: max_k y_k / t
     float mx = -INFINITY;
     for (int k = 0; k < n_bins; ++k) {
-      const float k_ = (float)k + eps;
-      const float logc = nlogn - k_ * logf(k_) - (n_ - k_) * logf(n_ - k_ + eps);
-      const float yk = (logc + (float)k * lp + (float)(n_bins - 1 - k) * lq) / t;
+      const float yk = (logc_tab[k] + (float)k * lp + (float)(n_bins - 1 - k) * lq) / t;
       mx = fmaxf(mx, yk);
     }
     const Lerp ly = ac_coord(oy, sh, hc), lx = ac_coord(ox, sw, wc);
@@ -542,9 +549,7 @@ __global__ void logbinom_depth_kernel(const float* __restrict__ pt, int pt_ld, c
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int k = k4 + e;
-        const float k_ = (float)k + eps;
-        const float logc = nlogn - k_ * logf(k_) - (n_ - k_) * logf(n_ - k_ + eps);
-        const float yk = (logc + (float)k * lp + (float)(n_bins - 1 - k) * lq) / t;
+        const float yk = (logc_tab[k] + (float)k * lp + (float)(n_bins - 1 - k) * lq) / t;
         const float pe = expf(yk - mx);
         const float c = ly.l0 * (lx.l0 * a00[e] + lx.l1 * a01[e]) + ly.l1 * (lx.l0 * a10[e] + lx.l1 * a11[e]);
         num += pe * c;
@@ -611,6 +616,161 @@ __global__ void resize_bilinear_f32_kernel(const float* __restrict__ x, int H, i
     const Lerp ly = ac_coord(oy, sh, H), lx = ac_coord(ox, sw, W);
     const float v00 = x[(long)ly.i0 * W + lx.i0], v01 = x[(long)ly.i0 * W + lx.i1], v10 = x[(long)ly.i1 * W + lx.i0], v11 = x[(long)ly.i1 * W + lx.i1];
     y[i] = ly.l0 * (lx.l0 * v00 + lx.l1 * v01) + ly.l1 * (lx.l0 * v10 + lx.l1 * v11);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Metric-bins head tail at full resolution, one launch (float32): the conditional log-binomial of zoedepth_v1.py:207-219 /
+// dist_layers.py:97-121 --  x = cat[last(32), rel?, up(b_embedding)(128)] -> Conv1x1(->80) + GELU -> Conv1x1(->4) + Softplus -> p, t ->
+// log-binomial softmax over 64 bins -> expectation over the bilinearly up-sampled bin centres.  Replaces four launches (resize of the
+// embedding into the CLB buffer, two pf_conv, pf_logbinom_depth) and their 160 / 80 / 4-channel full-resolution intermediates.
+//
+// A wave owns 16 pixels per step; lane (r = l & 15, g = l >> 4) holds for pixel r the channels 16 q + 4 g + e (e = 0..3) of every K group q:
+// exactly the B operand of v_mfma_f32_16x16x4_f32 for "step (q, e)", with the weights pre-packed to the same K permutation
+// (packing.bins_tail_weights: [nq][5 fragments][64 lanes][4]) and resident in LDS.  The operand is BUILT in registers straight from
+// global memory -- K groups 0-1 = `last` (16-byte loads from the CLB buffer), 2-9 = the embedding, blended from its four low-resolution taps
+// with the resize kernels' own expression (bit-identical to pf_resize_bilinear), 10 = rel -- so the up-sampled embedding never exists.  The
+// accumulators come out as 20 of the 80 hidden channels of the lane's pixel: bias + GELU in place, the 80 -> 4 layer as 80 FMAs per lane + two
+// xor-shuffles across the four lane groups, Softplus, then the 64 bins are split 16 per lane group for the log-binomial passes.
+constexpr int BT_HID_FRAGS = 5;        // 80 hidden channels
+constexpr int BT_MAXQ = 11;            // K groups of 16 channels: 32 last + 128 embedding (+ 8 rel)
+__global__ __launch_bounds__(256, 2) void bins_tail_kernel(const float* __restrict__ clb, int clb_ld, int rel_off, const float* __restrict__ emb,
+                                                           int he, int we, const float* __restrict__ w0f, const float* __restrict__ b0,
+                                                           const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ cen,
+                                                           int hc, int wc, float* __restrict__ depth, int B, int H, int W, int nq, float min_temp,
+                                                           float max_temp, float she, float swe, float shc, float swc) {
+  extern __shared__ __attribute__((aligned(16))) char bt_lds[];
+  float4* w0s = reinterpret_cast<float4*>(bt_lds);                                         // [nq][5][64]
+  float* w2s = reinterpret_cast<float*>(bt_lds + (size_t)nq * BT_HID_FRAGS * 64 * 16);     // [4][80]
+  float* logc = w2s + 320;                                                                 // [64]
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
+  for (int i = tid; i < nq * BT_HID_FRAGS * 64; i += blockDim.x) w0s[i] = reinterpret_cast<const float4*>(w0f)[i];
+  for (int i = tid; i < 320; i += blockDim.x) w2s[i] = w2[i];
+  const float eps = 1e-7f;
+  const float n_ = 63.0f + eps;
+  if (tid < 64) {
+    const float k_ = (float)tid + eps;
+    logc[tid] = n_ * logf(n_) - k_ * logf(k_) - (n_ - k_) * logf(n_ - k_ + eps);
+  }
+  __syncthreads();
+  float bias0[BT_HID_FRAGS][4];
+#pragma unroll
+  for (int f = 0; f < BT_HID_FRAGS; ++f)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bias0[f][e] = b0[16 * f + 4 * g + e];
+  const float b2r[4] = {b2[0], b2[1], b2[2], b2[3]};
+
+  const long total = (long)B * H * W;
+  const long ngroups = (total + 15) / 16;
+  const long gstride = (long)gridDim.x * 4;
+  for (long grp = (long)blockIdx.x * 4 + (tid >> 6); grp < ngroups; grp += gstride) {
+    const long pix_raw = grp * 16 + r;
+    const bool valid = pix_raw < total;
+    const long pix = valid ? pix_raw : total - 1;
+    const int ox = (int)(pix % W);
+    const int oy = (int)((pix / W) % H);
+    const int b = (int)(pix / ((long)W * H));
+    // ---- hidden layer: 80 x K on the f32 MFMA; the operand of K group q (channels 16 q + 4 g + e of this lane's pixel) is built just before
+    // its 20 MFMAs, the four embedding taps of the NEXT group already in flight (one group of look-ahead keeps the registers at ~130)
+    const float* cp = clb + pix * clb_ld + 4 * g;
+    const Lerp ly = ac_coord(oy, she, he), lx = ac_coord(ox, swe, we);
+    const float* e00 = emb + (((long)b * he + ly.i0) * we + lx.i0) * 128 + 4 * g;
+    const float* e01 = emb + (((long)b * he + ly.i0) * we + lx.i1) * 128 + 4 * g;
+    const float* e10 = emb + (((long)b * he + ly.i1) * we + lx.i0) * 128 + 4 * g;
+    const float* e11 = emb + (((long)b * he + ly.i1) * we + lx.i1) * 128 + 4 * g;
+    f32x4 acc[BT_HID_FRAGS];
+#pragma unroll
+    for (int f = 0; f < BT_HID_FRAGS; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 nx0 = *reinterpret_cast<const float4*>(cp), nx1, nx2, nx3;          // group 0 = last[0:16)
+#pragma unroll
+    for (int q = 0; q < BT_MAXQ; ++q) {
+      if (q < nq) {
+        float4 x;
+        if (q < 2 || q == 10) x = nx0;
+        else x = make_float4(bilerp(ly, lx, nx0.x, nx1.x, nx2.x, nx3.x), bilerp(ly, lx, nx0.y, nx1.y, nx2.y, nx3.y),
+                             bilerp(ly, lx, nx0.z, nx1.z, nx2.z, nx3.z), bilerp(ly, lx, nx0.w, nx1.w, nx2.w, nx3.w));
+        // look-ahead loads of group q + 1
+        if (q + 1 == 1) nx0 = *reinterpret_cast<const float4*>(cp + 16);
+        else if (q + 1 >= 2 && q + 1 < 10) {
+          nx0 = *reinterpret_cast<const float4*>(e00 + 16 * (q - 1));
+          nx1 = *reinterpret_cast<const float4*>(e01 + 16 * (q - 1));
+          nx2 = *reinterpret_cast<const float4*>(e10 + 16 * (q - 1));
+          nx3 = *reinterpret_cast<const float4*>(e11 + 16 * (q - 1));
+        } else if (q + 1 == 10 && nq > 10) {
+          nx0 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (g < 2) nx0 = *reinterpret_cast<const float4*>(clb + pix * clb_ld + rel_off + 4 * g);
+        }
+        const float xe[4] = {x.x, x.y, x.z, x.w};
+        float4 wf[BT_HID_FRAGS];
+#pragma unroll
+        for (int f = 0; f < BT_HID_FRAGS; ++f) wf[f] = w0s[(q * BT_HID_FRAGS + f) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int f = 0; f < BT_HID_FRAGS; ++f) {
+            const float we_ = e == 0 ? wf[f].x : (e == 1 ? wf[f].y : (e == 2 ? wf[f].z : wf[f].w));
+            acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(we_, xe[e], acc[f], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- bias + GELU, 80 -> 4, Softplus
+    float o4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int f = 0; f < BT_HID_FRAGS; ++f)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float t = gelu_erf(acc[f][e] + bias0[f][e]);
+        const int ch = 16 * f + 4 * g + e;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o4[c] += w2s[c * 80 + ch] * t;
+      }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      o4[c] += __shfl_xor(o4[c], 16, 64);
+      o4[c] += __shfl_xor(o4[c], 32, 64);
+      o4[c] = softplus20(o4[c] + b2r[c]);
+    }
+    // ---- log-binomial softmax over 64 bins (dist_layers.py:97-121), 16 bins per lane group
+    const float p0 = o4[0] + 1e-4f, p1 = o4[1] + 1e-4f, t0 = o4[2] + 1e-4f, t1 = o4[3] + 1e-4f;
+    float p = p0 / (p0 + p1);
+    float t = t0 / (t0 + t1);
+    t = (max_temp - min_temp) * t + min_temp;
+    const float omp = fminf(fmaxf(1.0f - p, 1e-4f), 1.0f);
+    p = fminf(fmaxf(p, 1e-4f), 1.0f);
+    const float lp = logf(p), lq = logf(omp);
+    float yk[16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int k = 16 * g + j;
+      yk[j] = (logc[k] + (float)k * lp + (float)(63 - k) * lq) / t;
+      mx = fmaxf(mx, yk[j]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const Lerp cy = ac_coord(oy, shc, hc), cx = ac_coord(ox, swc, wc);
+    const long cb = (long)b * hc * wc;
+    const float* c00 = cen + (cb + (long)cy.i0 * wc + cx.i0) * 64 + 16 * g;
+    const float* c01 = cen + (cb + (long)cy.i0 * wc + cx.i1) * 64 + 16 * g;
+    const float* c10 = cen + (cb + (long)cy.i1 * wc + cx.i0) * 64 + 16 * g;
+    const float* c11 = cen + (cb + (long)cy.i1 * wc + cx.i1) * 64 + 16 * g;
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int j4 = 0; j4 < 16; j4 += 4) {
+      float a00[4], a01[4], a10[4], a11[4];
+      load4(c00 + j4, a00); load4(c01 + j4, a01); load4(c10 + j4, a10); load4(c11 + j4, a11);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pe = expf(yk[j4 + e] - mx);
+        const float c = cy.l0 * (cx.l0 * a00[e] + cx.l1 * a01[e]) + cy.l1 * (cx.l0 * a10[e] + cx.l1 * a11[e]);
+        num += pe * c;
+        den += pe;
+      }
+    }
+    num += __shfl_xor(num, 16, 64); num += __shfl_xor(num, 32, 64);
+    den += __shfl_xor(den, 16, 64); den += __shfl_xor(den, 32, 64);
+    if (valid && g == 0) depth[pix] = num / den;
   }
 }
 
@@ -780,7 +940,7 @@ extern "C" int pf_bounded_bin_centers(const float* b, float* out, long npix, int
 
 extern "C" int pf_logbinom_depth(const float* pt, int pt_ld, const float* centers, int hc, int wc, float* depth, int B, int h, int w,
                                  int n_bins, float min_temp, float max_temp, void* stream) {
-  if (!pt || !centers || !depth || n_bins % 4) return PF_ERR_ARG;
+  if (!pt || !centers || !depth || n_bins % 4 || n_bins > 256) return PF_ERR_ARG;
   const long total = (long)B * h * w;
   hipLaunchKernelGGL(logbinom_depth_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ST(stream), pt, pt_ld, centers, hc, wc, depth, B, h, w, n_bins, min_temp, max_temp, ac_scale(hc, h), ac_scale(wc, w));
   return ok();
@@ -815,5 +975,28 @@ extern "C" int pf_resize_bilinear_f32(const float* x, int H, int W, float* y, in
   if (!x || !y) return PF_ERR_ARG;
   const long total = (long)OH * OW;
   hipLaunchKernelGGL(resize_bilinear_f32_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ST(stream), x, H, W, y, OH, OW, ac_scale(H, OH), ac_scale(W, OW));
+  return ok();
+}
+
+extern "C" int pf_bins_tail(const float* clb, int clb_ld, int rel_off, const float* emb, int he, int we, const float* w0f, const float* b0,
+                            const float* w2, const float* b2, const float* centers, int hc, int wc, float* depth, int B, int H, int W, int nq,
+                            float min_temp, float max_temp, void* stream) {
+  if (!clb || !emb || !w0f || !b0 || !w2 || !b2 || !centers || !depth || clb_ld % 4 || (nq != 10 && nq != 11) || (nq == 11 && (rel_off % 4 || rel_off + 8 > clb_ld)) ||
+      clb_ld < 32 || B <= 0 || H <= 0 || W <= 0)
+    return PF_ERR_ARG;
+  const size_t lds = (size_t)nq * BT_HID_FRAGS * 64 * 16 + 320 * 4 + 64 * 4;
+  static std::atomic<unsigned long long> done{0};
+  int dev = 0;
+  hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(bins_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    done.fetch_or(bit, std::memory_order_release);
+  }
+  const long groups = ((long)B * H * W + 15) / 16;
+  long blocks = (groups + 3) / 4;
+  blocks = blocks > 512 ? 512 : blocks;                     // two resident blocks per CU, each looping over its share of the pixels
+  hipLaunchKernelGGL(bins_tail_kernel, dim3((unsigned)blocks), dim3(256), lds, ST(stream), clb, clb_ld, rel_off, emb, he, we, w0f, b0, w2, b2, centers, hc,
+                     wc, depth, B, H, W, nq, min_temp, max_temp, ac_scale(he, H), ac_scale(we, W), ac_scale(hc, H), ac_scale(wc, W));
   return ok();
 }

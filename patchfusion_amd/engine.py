@@ -31,6 +31,12 @@ def linear_split3_enabled():
     return os.environ.get("PF_LINEAR_SPLIT3", "1") != "0"
 
 
+def bins_tail_enabled():
+    """float32 mode: the fused metric-bins tail kernel (pf_bins_tail)?  PF_BINS_TAIL=0 keeps the four separate launches"""
+    import os
+    return os.environ.get("PF_BINS_TAIL", "1") != "0"
+
+
 def _g(sd, name, device):
     return sd[name].detach().to(device=device, dtype=F32).contiguous()
 
@@ -78,6 +84,12 @@ class BinsHead:
         self.clb_channels = ctot
         self.mlp0 = pc("conditional_log_binomial.mlp.0", cin_map=cmap, cin_total=ctot)
         self.mlp2 = pc("conditional_log_binomial.mlp.2")
+        # float32: resize-into-CLB + mlp.0 + mlp.2 + log-binomial as ONE kernel (pf_bins_tail) when the head has the shipped shape
+        self.tail = None
+        if dtype == F32 and self.n_bins == 64 and bins_tail_enabled():
+            self.tail = pk.bins_tail_weights(self.mlp0, self.mlp2, self.emb)
+            if self.tail is not None:
+                self.tail = self.tail.to(device)
 
     def new_clb_buffer(self, ops, B, H, W):
         return ops.empty((B, H, W, self.clb_channels), self.dtype, self.device)
@@ -122,6 +134,12 @@ class BinsHead:
             if taps is not None:
                 taps[f"bins_centers{i}"] = b_new
         _, H, W, _ = clb.shape
+        if self.tail is not None and emb.is_contiguous():
+            if self.attr_bounded:
+                b_prev = ops.bounded_bin_centers(b_prev, ops.empty(tuple(b_prev.shape), F32, dev), self.lo, self.hi)
+            depth = ops.empty((B, H, W), F32, dev)
+            ops.bins_tail(clb, emb, self.tail, b_prev, depth, self.min_temp, self.max_temp)
+            return depth
         ops.resize(emb, clb[..., 32:32 + self.emb])                 # b_embedding upsampled to (H, W)
         t = ops.empty((B, H, W, self.mlp0.cout), dt, dev)
         ops.conv(clb, self.mlp0, t, act="gelu")

@@ -460,6 +460,18 @@ class HipOps:
         check(_L.pf_logbinom_depth(_p(pt), _ld(pt), _p(centers), hc, wc, _p(depth), B, h, w, nb, float(min_temp), float(max_temp), _stream()),
               "pf_logbinom_depth")
 
+    @staticmethod
+    def bins_tail(clb, emb, tw, centers, depth, min_temp, max_temp):
+        """clb [B,H,W,ctot] f32 (channels [0,32) = last, [160,168) = rel when tw.nq == 11; the embedding slice is NOT read); emb [B,he,we,128]
+        f32; tw packing.BinsTail; centers [B,hc,wc,64] f32; depth [B,H,W] f32"""
+        B, H, W, _ = clb.shape
+        _, he, we, ce = emb.shape
+        _, hc, wc, nb = centers.shape
+        assert clb.dtype == emb.dtype == centers.dtype == depth.dtype == torch.float32 and ce == 128 and nb == 64
+        assert emb.is_contiguous() and centers.is_contiguous() and depth.is_contiguous() and clb.stride(3) == 1
+        check(_L.pf_bins_tail(_p(clb), _ld(clb), tw.rel_off, _p(emb), he, we, _p(tw.w0f), _p(tw.b0), _p(tw.w2), _p(tw.b2), _p(centers), hc, wc,
+                              _p(depth), B, H, W, tw.nq, float(min_temp), float(max_temp), _stream()), "pf_bins_tail")
+
     # ---------------- stitching ----------------
     @staticmethod
     def stitch_init(pred, count, depth, mask, yx):

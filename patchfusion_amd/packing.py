@@ -238,6 +238,41 @@ def unpack_conv(pc: PackedConv):
     return w.reshape(pc.cout, pc.KH, pc.KW, pc.cin).permute(0, 3, 1, 2).contiguous()
 
 
+@dataclass
+class BinsTail:
+    """Weights of the fused metric-bins tail kernel (csrc/imageops.hip bins_tail_kernel): the two 1x1 layers of the conditional log-binomial
+    MLP (zoedepth_v1.py:207-213, dist_layers.py:97-110) in the kernel's order.  `mlp0` / `mlp2` are kept for the test back-end."""
+    w0f: torch.Tensor               # [nq, 5, 64, 4] float32: lane (r = l & 15, g = l >> 4) of fragment f, K group q: W0[16 f + r][16 q + 4 g + e]
+    b0: torch.Tensor                # [80]
+    w2: torch.Tensor                # [4, 80]
+    b2: torch.Tensor                # [4]
+    nq: int                         # K groups of 16 CLB-buffer channels (10: last + embedding; 11: + rel)
+    rel_off: int                    # channel offset of rel in the CLB buffer (nq == 11)
+    mlp0: PackedConv
+    mlp2: PackedConv
+
+    def to(self, device):
+        self.w0f, self.b0, self.w2, self.b2 = (t.to(device) for t in (self.w0f, self.b0, self.w2, self.b2))
+        return self
+
+
+def bins_tail_weights(mlp0: PackedConv, mlp2: PackedConv, emb: int):
+    """-> BinsTail, or None when the head is not the shape the fused kernel is written for (float32, 32 `last` channels + 128 embedding
+    channels (+ 8 rel) -> 80 hidden -> 4)."""
+    if mlp0.w.dtype != torch.float32 or mlp0.KH != 1 or mlp2.KH != 1 or emb != 128 or mlp0.cout_real != 80 or mlp2.cout_real != 4:
+        return None
+    if mlp0.cin not in (160, 168) or mlp2.cin != 80 or mlp0.bias is None or mlp2.bias is None or mlp0.scale is not None or mlp2.scale is not None:
+        return None
+    W0 = unpack_conv(mlp0).cpu()[:80, :, 0, 0]                      # [80, ctot] over the CLB buffer's channel order
+    ctot = W0.shape[1]
+    nq = (ctot + 15) // 16
+    Wp = torch.zeros(80, nq * 16)
+    Wp[:, :ctot] = W0
+    w0f = Wp.view(5, 16, nq, 4, 4).permute(2, 0, 3, 1, 4).reshape(nq, 5, 64, 4).contiguous()       # (f, r, q, g, e) -> (q, f, g, r, e)
+    W2 = unpack_conv(mlp2).cpu()[:4, :80, 0, 0].contiguous()
+    return BinsTail(w0f, mlp0.bias.cpu()[:80].clone().float(), W2, mlp2.bias.cpu()[:4].clone().float(), nq, 160, mlp0, mlp2)
+
+
 def vit_pos_embed(pos_embed, th, tw):
     """interpolate_pos_encoding (vision_transformer.py:179-210): bicubic resample of the stored
     37x37 grid to (th, tw) with the +0.1 offset passed through ``scale_factor``.  It depends only on

@@ -116,6 +116,18 @@ class FakeOps:
         y4[..., :n] = v.to(y4.dtype)
         return y
 
+    @staticmethod
+    def bins_tail(clb, emb, tw, centers, depth, min_temp, max_temp):
+        """the four steps the fused kernel replaces, with the packed layers it was built from"""
+        B, H, W, _ = clb.shape
+        buf = clb.clone()
+        FakeOps.resize(emb, buf[..., 32:32 + emb.shape[-1]])
+        t = torch.zeros((B, H, W, tw.mlp0.cout), dtype=torch.float32, device=clb.device)
+        FakeOps.conv(buf, tw.mlp0, t, act="gelu")
+        pt = torch.zeros((B, H, W, tw.mlp2.cout), dtype=torch.float32, device=clb.device)
+        FakeOps.conv(t, tw.mlp2, pt, act="softplus")
+        FakeOps.logbinom_depth(pt, centers, depth, min_temp, max_temp)
+
     # ---- split-precision linears: the planes are summed back to float32 (exact) and the layer evaluated in plain float32 ----
     @staticmethod
     def _store3(y3, v):

@@ -637,6 +637,44 @@ def bins_ops(dt):
     return max(errs), 1e-4, "attractor/logbinom"
 
 
+def bins_tail(dt):
+    """the fused metric-bins tail (pf_bins_tail) against the four launches it replaces (HIP kernels) and against the torch reference of
+    those (tests/fake_ops.py): with and without the rel channels, a pixel count that is not a multiple of the 16-pixel wave step"""
+    o = hip()
+    g = torch.Generator().manual_seed(91)
+    errs, info = [], []
+    for ctot in (168, 160):
+        B, H, W, he, we = 2, 37, 50, 21, 29
+        w0 = torch.randn(80, ctot, 1, 1, generator=g) / ctot ** 0.5
+        w2 = torch.randn(4, 80, 1, 1, generator=g) / 80 ** 0.5
+        mlp0 = pk.pack_conv(w0, torch.randn(80, generator=g) * 0.1, dtype=torch.float32).to(DEV)
+        mlp2 = pk.pack_conv(w2, torch.randn(4, generator=g) * 0.1, dtype=torch.float32).to(DEV)
+        tw = pk.bins_tail_weights(mlp0, mlp2, 128)
+        assert tw is not None and tw.nq == (11 if ctot == 168 else 10)
+        tw = tw.to(DEV)
+        clb = torch.randn(B, H, W, ctot, generator=g).to(DEV)
+        clb[..., 32:160] = 123.0                                  # the embedding slice of the buffer must NOT be read by the fused kernel
+        emb = torch.randn(B, he, we, 128, generator=g).to(DEV)
+        cen = (torch.rand(B, he, we, 64, generator=g) * 5 + 0.5).sort(-1).values.contiguous().to(DEV)
+        d_f = torch.zeros(B, H, W, device=DEV)
+        o.bins_tail(clb, emb, tw, cen, d_f, 0.0212, 50.0)
+        outs = []
+        for oo in (o, ref_ops):
+            buf = clb.clone()
+            oo.resize(emb, buf[..., 32:160])
+            t = torch.zeros(B, H, W, 80, device=DEV)
+            oo.conv(buf, mlp0, t, act="gelu")
+            pt = torch.zeros(B, H, W, 4, device=DEV)
+            oo.conv(t, mlp2, pt, act="softplus")
+            d = torch.zeros(B, H, W, device=DEV)
+            oo.logbinom_depth(pt, cen, d, 0.0212, 50.0)
+            outs.append(d)
+        e_hip, e_ref = _err(d_f, outs[0]), _err(d_f, outs[1])
+        errs += [e_hip, e_ref]
+        info.append(f"ctot {ctot}: vs four HIP launches {e_hip:.2e}, vs torch {e_ref:.2e}")
+    return max(errs), 1e-4, "; ".join(info)
+
+
 def stitch_ops(dt):
     ph, pw = 28, 42
     depth = torch.rand(6, ph, pw, generator=torch.Generator().manual_seed(1)).to(DEV) + 0.5
@@ -674,7 +712,7 @@ CHECKS = {
     "conv_gemm_vitl_linear_shape": conv_gemm_vitl_linear_shape, "conv_dominant_launch": conv_dominant_launch,
     "conv_transpose": conv_transpose, "patch_embed_tokens": patch_embed_tokens, "layernorm": layernorm,
     "vit_attention": vit_attention, "vit_attention_split": vit_attention_split, "gemm_split3": gemm_split3, "swin_ops": swin_ops, "resize_ops": resize_ops, "roi_ops": roi_ops,
-    "conv_winograd": conv_winograd, "conv_winograd_fused": conv_winograd_fused, "misc_ops": misc_ops, "bins_ops": bins_ops, "stitch_ops": stitch_ops,
+    "conv_winograd": conv_winograd, "conv_winograd_fused": conv_winograd_fused, "misc_ops": misc_ops, "bins_ops": bins_ops, "bins_tail": bins_tail, "stitch_ops": stitch_ops,
 }
-F32_ONLY = {"bins_ops", "stitch_ops", "conv_winograd", "conv_winograd_fused", "vit_attention_split", "gemm_split3"}
+F32_ONLY = {"bins_ops", "bins_tail", "stitch_ops", "conv_winograd", "conv_winograd_fused", "vit_attention_split", "gemm_split3"}
 DTYPES = {"fp32": torch.float32, "bf16": torch.bfloat16}

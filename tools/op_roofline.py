@@ -55,6 +55,8 @@ def sig(v):
         return ("W", v.cin, v.cout, v.KH, v.KW, v.shuffle, tuple(v.w.shape))
     if isinstance(v, (tuple, list)):
         return tuple(sig(x) for x in v)
+    if type(v).__name__ == "BinsTail":
+        return ("BT", v.nq)
     return v
 
 
@@ -135,6 +137,11 @@ def work(name, a, k):
     if name == "attractor":
         A, n_attr, b_prev, out = a[:4]
         return "byte", nbytes(A, n_attr) + nbytes(b_prev) + nbytes(out), f"{tuple(out.shape)} n_attr{n_attr}"
+    if name == "bins_tail":
+        clb, emb, tw, cen, depth = a[:5]
+        ct = 160 if tw.nq == 10 else 168
+        fl = 2.0 * depth.numel() * (ct * 80 + 80 * 4)
+        return "flop", fl, f"{tuple(depth.shape)} [{ct}->80->4 + log-binomial, embedding / centres from {tuple(emb.shape[1:3])}; rate = the two layers' FLOPs / time]"
     if name == "logbinom_depth":
         pt, centers, depth = a[:3]
         return "byte", nbytes(pt, 4) + nbytes(centers) + nbytes(depth), f"{tuple(depth.shape)} centres {tuple(centers.shape[1:3])}"

@@ -255,7 +255,9 @@ def roofline(dtype, dev, gemm_only=False):
     whole three-step layer: its time and the direct-convolution FLOPs it replaces per second (which may exceed the MFMA peak:
     Winograd multiplies (m+2)^2 / (9 m^2) as often).  PF_WINOGRAD=0: the direct f32 kernel on the 3x3 layer, as in bf16.
     `traffic` (HBM bytes per launch from the rocprofv3 PMC passes, which cannot run inside bench.py) is reported only when
-    profiles/r2_pmc_dominant_<dtype>.json was measured on EXACTLY this kernel source (sha of igemm.hip); otherwise null."""
+    profiles/r3_pmc_dominant_<dtype>.json was measured on EXACTLY this kernel source (sha of igemm.hip + wino_fused.hip + pf_common.h); otherwise null.
+    NOTE on its meaning: FETCH_SIZE / WRITE_SIZE count the L2's fabric-side requests; reads served by the 256 MiB Infinity Cache are included, so
+    for the fused Winograd kernel (whose 43 MB filter set and 10 MB halo groups are re-streamed through L2 by design) it is an UPPER bound on HBM bytes."""
     from patchfusion_amd import packing as pk
     from patchfusion_amd.hip_ops import ops
     tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
@@ -265,7 +267,7 @@ def roofline(dtype, dev, gemm_only=False):
     peak = PEAK_TFLOPS[dtype]
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", f"r2_pmc_dominant_{dtype}.json")) as f:
+        with open(os.path.join(ROOT, "profiles", f"r3_pmc_dominant_{dtype}.json")) as f:
             j = json.load(f)
         if j.get("kernel_source_sha") == kernel_source_sha() and j.get("winograd_m", 0) == pw.wino_m:
             traffic = j["derived"]["traffic_bytes"]

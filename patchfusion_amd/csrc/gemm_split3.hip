@@ -43,7 +43,14 @@ __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :
 // barrier that does not drain the DMA queue (__syncthreads may be lowered with s_waitcnt vmcnt(0))
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int BM, int BN, int WM, int WN, int NS>
+// barrier without waiting for this wave's own LDS reads (ping-pong schedule: the reads issued just before it may stay in flight)
+__device__ __forceinline__ void plain_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_barrier" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int BM, int BN, int WM, int WN, int NS, bool PP = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_split3_kernel(const pf_conv_params p) {
   constexpr int NW = WM * WN, NT = 64 * NW;
   constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 16, FN = WTN / 16;
@@ -168,7 +175,42 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split3_kernel(const pf_conv
     }
     multiply(cur);
   };
-  if constexpr (NS == 3) {
+  if constexpr (NS == 3 && PP) {
+    // PING-PONG: the two waves of a SIMD (wave w and w + NW/2) run the same loop ONE PHASE apart.  A chunk is two phases separated by
+    // barriers -- M(kc): issue the DMA pieces of chunk kc+3, read the fragments of chunk kc+1, wait for this wave's pieces of chunk kc+2;
+    // C(kc): the 48 MFMAs of chunk kc out of registers -- and group B enters the loop one barrier later than group A, so that in every phase
+    // one wave of each SIMD feeds the matrix pipe while the other does its loads.  Hazards (phases numbered globally, A: M(kc) = 2kc,
+    // B: M(kc) = 2kc+1): chunk kc+1 is read in M(kc); its pieces were waited for at the end of M(kc-1) by both groups (phases 2kc-2, 2kc-1);
+    // the slot of chunk kc is overwritten from phase 2kc on, after its last read in phase 2kc-1 (lgkmcnt(0) before that phase's barrier).
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+      if (i < nk) issue(i);
+    if (nk > 2) vm_wait<PPW>();                         // chunks 0 and 1 landed
+    else vm_wait<0>();
+    lds_barrier();
+    Frags fa, fb;
+    read_frags(fa, 0);
+    lds_barrier();
+    const bool grp_b = wave >= NW / 2;
+    if (grp_b) plain_barrier();                         // one phase behind
+    auto pp_chunk = [&](const Frags& cur, Frags& nxt, int kc) {
+      if (kc + 3 < nk) issue(kc % NS);
+      if (kc + 1 < nk) read_frags(nxt, kc + 1);
+      if (kc + 3 < nk) vm_wait<PPW>();
+      else if (kc + 2 < nk) vm_wait<0>();
+      lds_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      multiply(cur);
+      __builtin_amdgcn_s_setprio(0);
+      plain_barrier();
+    };
+    for (int kc = 0; kc < nk; kc += 2) {
+      pp_chunk(fa, fb, kc);
+      if (kc + 1 < nk) pp_chunk(fb, fa, kc + 1);
+    }
+    if (!grp_b) plain_barrier();
+  } else if constexpr (NS == 3) {
 #pragma unroll
     for (int i = 0; i < NS; ++i)
       if (i < nk) issue(i);
@@ -233,14 +275,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split3_kernel(const pf_conv
 
 thread_local char g_err[200] = {0};
 
-template <int BM, int BN, int WM, int WN, int NS>
+template <int BM, int BN, int WM, int WN, int NS, bool PP = false>
 int launch(const pf_conv_params& p, hipStream_t st) {
   constexpr int smem = NS * 3 * (BM + BN) * 64;
   static std::atomic<unsigned long long> done{0};
   int dev = 0;
   hipGetDevice(&dev);
   const unsigned long long bit = 1ull << (dev & 63);
-  auto kern = gemm_split3_kernel<BM, BN, WM, WN, NS>;
+  auto kern = gemm_split3_kernel<BM, BN, WM, WN, NS, PP>;
   if (!(done.load(std::memory_order_acquire) & bit)) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     done.fetch_or(bit, std::memory_order_release);
@@ -271,13 +313,15 @@ extern "C" int pf_gemm_split3(const pf_conv_params* p, void* stream) {
   else if (p->x_bstride <= 0 || p->w_bstride <= 0 || (!p->out_f32 && p->y_bstride <= 0)) e = "plane strides missing";
   if (e) return PF_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  // tile: 128 x 128 (eight waves, one block per CU) unless the token x channel grid is too small to fill the chip twice; PF_S3_TILE_NOW forces
+  // tile: 128 x 128 (eight waves, one block per CU, ping-pong) unless the token x channel grid does not fill the chip once; PF_S3_TILE_NOW forces
   int force = 0;
   if (const char* s = getenv("PF_S3_TILE_NOW")) force = atoi(s);      // (tests: read per call)
   const long M = (long)p->B * p->OH * p->OW;
   const long t128 = ((M + 127) / 128) * ((p->Cout + 127) / 128);
-  const bool small = force ? force == 64 : t128 < 512;
-    return small ? launch<64, 128, 2, 2, 2>(*p, st) : launch<128, 128, 4, 2, 3>(*p, st);
+  const bool small = force ? force == 64 : t128 < 256;       // (ping-pong 128 x 128 wins from one full round of tiles on: profiles/r3_split3_pingpong.log)
+    if (small) return launch<64, 128, 2, 2, 2>(*p, st);
+  const char* pp = getenv("PF_S3_PP");                    // (A/B switch; read per call)
+  return (pp && pp[0] == '0') ? launch<128, 128, 4, 2, 3, false>(*p, st) : launch<128, 128, 4, 2, 3, true>(*p, st);
 }
 
 extern "C" int pf_gemm_split3_timed(const pf_conv_params* p, int iters, float* ms, void* stream) {

@@ -85,7 +85,7 @@ int pf_conv_winograd_fused(const pf_conv_params* p, const void* up, int nnb, int
 /* timing helper like pf_conv_timed: `iters` launches bracketed by HIP events on `stream` */
 int pf_conv_winograd_fused_timed(const pf_conv_params* p, const void* up, int nnb, int gs, int iters, float* ms, void* stream);
 
-/* ---- split-precision linear layer ("f32x3", exploratory mode; csrc/gemm_split3.hip) --------------------------------------------
+/* ---- split-precision linear layer (csrc/gemm_split3.hip; the float32 mode's ViT block linears) --------------------------------------------
  * float32-grade y = epi(x . w^T) on the bf16 matrix cores: x and w are given as THREE bf16 planes each (x = x_h + x_m + x_l, round-to-
  * nearest splits) and the six leading partial products are accumulated in float32.  `p` as for pf_conv with KH = KW = 1: x = planes
  * [3][M][x_ld] bf16 (plane stride x_bstride elements), w = planes [3][w_rows][Kpad] bf16 (w_bstride; packing.pack_conv_split3), Cin % 32

@@ -1,9 +1,10 @@
-// Split-precision linear layer: float32-grade GEMM on the bf16 matrix cores ("f32x3" mode, EXPLORATORY -- never the default).
+// Split-precision linear layer: float32-grade GEMM on the bf16 matrix cores.  Default for the ViT block linears of the float32 mode since its
+// error against float64 was measured equal to the f32 MFMA kernel's (tests/op_checks.py gemm_split3); PF_LINEAR_SPLIT3=0 turns it off.
 //
 // The f32 MFMA (v_mfma_f32_16x16x4_f32) runs at 1/16 of the bf16 rate, and the ViT-L linear layers (dinov2/layers/attention.py:51,60,
 // mlp.py:35-41: qkv / proj / fc1 / fc2, 29 % of the float32 image pass) already sit at 0.69-0.78 of that peak.  Here every float32
-// operand is carried as THREE bf16 planes  x = x_h + x_m + x_l  (round-to-nearest splits: 8 + 8 + 8 significant bits, exact for every
-// normal float32) and the product is evaluated as the six leading partial products
+// operand is carried as THREE bf16 planes  x = x_h + x_m + x_l  (round-to-nearest splits: 8 + 8 + 8 significant bits, exact for
+// 1e-30 < |x| < 3.39e38, the bf16 maximum) and the product is evaluated as the six leading partial products
 //     x.w ~= x_l.w_h + x_h.w_l + x_m.w_m + x_m.w_h + x_h.w_m + x_h.w_h          (dropped: x_m.w_l, x_l.w_m, x_l.w_l <= 2^-24 |x||w|)
 // on v_mfma_f32_16x16x32_bf16 with float32 accumulators, smallest terms first.  Each bf16 x bf16 product is exact in float32, so the
 // result differs from the float32 FMA chain by a few 2^-24 relative to sum |x||w| -- float32 rounding class, not bf16 (measured against

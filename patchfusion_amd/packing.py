@@ -176,7 +176,7 @@ def pack_conv(weight, bias=None, *, dtype, cin_map=None, cin_total=None, scale=N
 
 
 def split3(x):
-    """float32 tensor -> three bfloat16 tensors (h, m, l) with h + m + l == x for every normal float32 (round-to-nearest splits)"""
+    """float32 tensor -> three bfloat16 tensors (h, m, l) with h + m + l == x exactly for 1e-30 < |x| < 3.39e38 = the bf16 maximum (round-to-nearest splits; beyond that range the leading plane overflows / the third plane underflows)"""
     x = x.float()
     h = x.to(torch.bfloat16)
     r = x - h.float()

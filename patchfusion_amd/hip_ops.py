@@ -167,6 +167,12 @@ class HipOps:
             check(_L.pf_conv_winograd_fused_timed(C.byref(p), _p(pw.wino_up), nnb, gs, int(_timed), C.byref(ms), _stream()),
                   "pf_conv_winograd_fused_timed")
             return ms.value
+        if wino and pw.wino_u is None:
+            wino = False                                      # fused-only layer below the block threshold: direct kernel
+            if _timed is not None:
+                ms = C.c_float(0)
+                check(_L.pf_conv_timed(C.byref(p), int(_timed), C.byref(ms), _stream()), "pf_conv_timed")
+                return ms.value
         if wino:
             # float32 3x3 layers with enough pixels: input transform -> (m+2)^2 GEMMs -> output transform (csrc/winograd.hip)
             m = pw.wino_m

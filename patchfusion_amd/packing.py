@@ -84,12 +84,23 @@ def winograd_eligible(cout_store, cin_total, KH, KW, dtype):
     return dtype == torch.float32 and KH == 3 and KW == 3 and cin_total % 32 == 0 and cin_total >= 128 and cout_store % 32 == 0
 
 
+def winograd_fused_only_eligible(cout_store, cin_total, KH, KW, dtype):
+    """3x3 float32 layers BELOW the three-step form's channel threshold (32 <= Cin < 128, or Cout not a multiple of 32) that the fused
+    kernel (csrc/wino_fused.hip) can still take: Cin a multiple of 16, Cout of 4.  They get the fused filters only; whether a call uses
+    them is decided per call (hip_ops._fused_wanted: enough blocks), otherwise the direct kernel runs.  PF_WINO_FUSED_SMALL=0 disables."""
+    import os
+    if os.environ.get("PF_WINO_FUSED_SMALL", "1") == "0" or winograd_mode() != 4:
+        return False
+    return (dtype == torch.float32 and KH == 3 and KW == 3 and cin_total % 16 == 0 and cin_total >= 32 and cout_store % 4 == 0 and
+            not winograd_eligible(cout_store, cin_total, KH, KW, dtype))
+
+
 def winograd_applies(pc, pixels, stride, pad, act):
     """call-time half of the eligibility: the layer was packed with Winograd filters and this call is a 3x3 / stride 1 / pad 1
     convolution over at least PF_WINOGRAD_MIN_PIXELS pixels (default 0: measured 1.4 .. 4x the direct kernel on every eligible layer of the pass, from 8x392x518 down to 1x14x19, profiles/r2c_wino_tune.log) whose
     epilogue the output transform implements (bias, ReLU, residuals)."""
     import os
-    if pc.wino_u is None or stride != 1 or pad != 1 or act not in (None, "none", "relu"):
+    if (pc.wino_u is None and pc.wino_up is None) or stride != 1 or pad != 1 or act not in (None, "none", "relu"):
         return False
     return pixels >= int(os.environ.get("PF_WINOGRAD_MIN_PIXELS", "0"))
 
@@ -172,6 +183,8 @@ def pack_conv(weight, bias=None, *, dtype, cin_map=None, cin_total=None, scale=N
     wm = winograd_mode() if (scale is None and winograd_eligible(cout_store, cin_total, KH, KW, dtype)) else 0
     wu = winograd_filters(wk, wm) if wm else None
     wup = winograd_filters_fused(wk) if wm == 4 else None
+    if wm == 0 and scale is None and winograd_fused_only_eligible(cout_store, cin_total, KH, KW, dtype):
+        wm, wup = 4, winograd_filters_fused(wk)                   # fused kernel only (wino_u stays None: no three-step form)
     return PackedConv(wp.to(dtype).contiguous(), bp, sp, KH, KW, cin_total, cout_store, cout, korder=korder, wino_m=wm, wino_u=wu, wino_up=wup)
 
 

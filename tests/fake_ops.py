@@ -90,7 +90,7 @@ class FakeOps:
         if relu_in:
             xin = F.relu(xin)
         s = pw.shuffle
-        if (os.environ.get("PF_FAKE_WINOGRAD") == "1" and not _direct and not xin.is_cuda and
+        if (os.environ.get("PF_FAKE_WINOGRAD") == "1" and not _direct and not xin.is_cuda and pw.wino_u is not None and
                 winograd_applies(pw, xin.shape[0] * xin.shape[2] * xin.shape[3], stride, pad, act)):
             # opt-in for the CPU wiring tests of the Winograd path (tests/test_winograd_cpu.py, one end-to-end case): the three steps
             # with the PACKED filters.  Everywhere else -- and always on the GPU, where this class is the CHECKER of the HIP kernels --

@@ -72,7 +72,7 @@ def work(name, a, k):
         from patchfusion_amd import hip_ops
         fused = wino and pw.wino_up is not None and hip_ops._fused_wanted(x4.shape[0], x4.shape[1], x4.shape[2], pw.cin, pw.cout)
         tag = ""
-        if wino:
+        if wino and (fused or pw.wino_u is not None):
             tag = (f" [winograd F{pw.wino_m} FUSED kernel, rate = direct-conv FLOPs / time]" if fused else
                    f" [winograd F{pw.wino_m}: 3 steps, rate = direct-conv FLOPs / time]")
         return "flop", fl, f"{tuple(x4.shape[:3])} {pw.cin}->{pw.cout} k{pw.KH} s{k.get('stride', 1)}" + (" convT" if s > 1 else "") + tag

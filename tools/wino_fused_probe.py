@@ -92,6 +92,8 @@ SHAPES = {
     "c256_256_L4": (8, 224, 296, 256, 256), "c768_768_L2": (8, 56, 74, 768, 768), "c128_32": (8, 392, 518, 128, 32),
     "c256_256_L3": (8, 112, 148, 256, 256), "c256_128_L4": (8, 224, 296, 256, 128), "c512_256_L2": (8, 56, 74, 512, 256),
     "c256_256_B1": (1, 224, 296, 256, 256), "c768_768_L1": (8, 28, 37, 768, 768),
+    # below the three-step form's channel threshold: fused kernel against the DIRECT kernel (the "three-step" column is the direct kernel there)
+    "c64_32": (8, 392, 518, 64, 32), "c32_32": (8, 392, 518, 32, 32), "c32_256": (8, 196, 259, 32, 256), "c64_64_L4": (8, 224, 296, 64, 64),
 }
 
 

@@ -93,6 +93,9 @@ int pf_conv_winograd_fused_timed(const pf_conv_params* p, const void* up, int nn
  * following split GEMM.  Same reference layers as pf_conv's linear use (attention.py:51,60, mlp.py:35-41). */
 int pf_gemm_split3(const pf_conv_params* p, void* stream);
 int pf_gemm_split3_timed(const pf_conv_params* p, int iters, float* ms, void* stream);
+/* A plain bf16 linear layer (x [M][x_ld] bf16, w from packing.pack_conv, bf16 residuals / output, float32 output when out_f32) through the same
+ * ping-pong LDS-DMA pipeline: 256 x 128 tiles, Cin % 64 == 0.  The bf16 mode's ViT block linears at large token counts (same reference layers). */
+int pf_gemm_bf16_pp(const pf_conv_params* p, void* stream);
 /* the split producers of the ViT block: LayerNorm (layers/block.py:88-93 norm1 / norm2) and the attention output (attention.py:58-60)
  * written as three bf16 planes; arguments as pf_layernorm (plain row range) / pf_vit_attention_qkv with the plane stride in elements */
 int pf_layernorm_split3(const float* x, int x_ld, void* y3, int y_ld, long plane, const float* g, const float* b, float eps, long rows,

@@ -51,11 +51,15 @@ __device__ __forceinline__ void plain_barrier() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool PP = false>
+// NP = bf16 planes per operand and stage.  PLAIN = false: the split-precision GEMM (NP = 3 planes h / m / l, six cross terms, float32 residuals,
+// float32 or three-plane output).  PLAIN = true: an ordinary bf16 GEMM through the same pipeline -- the "planes" are NP consecutive 32-deep K
+// sub-chunks of ONE bf16 matrix (plane stride = 32 elements, the stage advances K by 32 NP), the terms are the NP diagonal products, residuals
+// and output are bf16 (float32 output when out_f32).
+template <int BM, int BN, int WM, int WN, int NS, bool PP = false, int NP = 3, bool PLAIN = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_split3_kernel(const pf_conv_params p) {
   constexpr int NW = WM * WN, NT = 64 * NW;
   constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 16, FN = WTN / 16;
-  constexpr int ROWS = 3 * (BM + BN), PIECES = ROWS / 16, PPW = PIECES / NW;      // 16 rows of 64 B per 1-KiB DMA piece
+  constexpr int ROWS = NP * (BM + BN), PIECES = ROWS / 16, PPW = PIECES / NW;      // 16 rows of 64 B per 1-KiB DMA piece
   constexpr int STAGE = ROWS * 64;
   static_assert(PIECES % NW == 0 && BM % 16 == 0 && BN % 16 == 0 && WTM % 16 == 0 && WTN % 16 == 0, "tile shape");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -88,15 +92,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split3_kernel(const pf_conv
     const int row = (wave * PPW + i) * 16 + (lane >> 2);        // row of the stage: [X plane 0..2 | W plane 0..2]
     const int j = (lane & 3) ^ ((row >> 1) & 3);
     const char* src = zero;
-    if (row < 3 * BM) {
+    if (row < NP * BM) {
       const int pl = row / BM, m = m0 + (row - pl * BM);
       if (m < M) src = reinterpret_cast<const char*>(xg + (size_t)pl * p.x_bstride + (size_t)m * p.x_ld + j * 8);
     } else {
-      const int rw = row - 3 * BM, pl = rw / BN, n = n0 + (rw - pl * BN);
+      const int rw = row - NP * BM, pl = rw / BN, n = n0 + (rw - pl * BN);
       if (n < p.w_rows) src = reinterpret_cast<const char*>(wg + (size_t)pl * p.w_bstride + (size_t)n * p.Kpad + j * 8);
     }
     cur[i] = src;
-    inc[i] = src == zero ? 0 : 64;
+    inc[i] = src == zero ? 0 : (PLAIN ? 64 * NP : 64);
   }
   const unsigned smem_base = lds_addr(smem);
 #ifdef PF_S3_DBG           // timing decomposition (results wrong by construction): env PF_S3_DBG bit 0 = no DMA after the first ring fill,
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split3_kernel(const pf_conv
   const int fr = lane & 15, fg = lane >> 4;
   const int slot = (fg ^ ((fr >> 1) & 3)) << 4;                    // fragment rows are multiples of 16 apart: the swizzle term is per lane
   const int x_off = (wm * WTM + fr) * 64 + slot;                   // + plane * BM * 64 + fm * 1024
-  const int w_off = 3 * BM * 64 + (wn * WTN + fr) * 64 + slot;     // + plane * BN * 64 + fn * 1024
+  const int w_off = NP * BM * 64 + (wn * WTN + fr) * 64 + slot;     // + plane * BN * 64 + fn * 1024
   // per-channel epilogue constants before the K loop (their latency hides behind it)
   float4 bias_r[FN], scale_r[FN];
 #pragma unroll
@@ -143,13 +147,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split3_kernel(const pf_conv
   // Ring of NS = 3 stage slots, fragments double-buffered in registers: while chunk kc is multiplied out of registers, the fragments of chunk
   // kc+1 are read from LDS (the matrix pipe never waits for ds_read), chunk kc+2 is in flight and chunk kc+3 is issued into the slot chunk kc
   // just left.  ONE barrier per chunk: it publishes stage kc+1 and retires the reads of stage kc.
-  const int nk = p.Cin / 32;
-  struct Frags { uint4 w[3][FN], x[3][FM]; };
+  const int nk = PLAIN ? p.Cin / (32 * NP) : p.Cin / 32;
+  struct Frags { uint4 w[NP][FN], x[NP][FM]; };
   auto read_frags = [&](Frags& f, int kc) {
     if (S3_DBG(4) && kc > 1) return;
     const char* S = smem + (kc % NS) * STAGE;
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
+    for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
       for (int fn = 0; fn < FN; ++fn) f.w[pl][fn] = *reinterpret_cast<const uint4*>(S + w_off + pl * (BN * 64) + fn * 1024);
 #pragma unroll
@@ -163,7 +167,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split3_kernel(const pf_conv
   _Pragma("unroll") for (int fn = 0; fn < FN; ++fn) _Pragma("unroll") for (int fm = 0; fm < FM; ++fm)                       \
       acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.w[PW][fn]), __builtin_bit_cast(bf16x8, f.x[PX][fm]), \
                                                             acc[fn][fm], 0, 0, 0);
-    S3_TERM(0, 2) S3_TERM(2, 0) S3_TERM(1, 1) S3_TERM(0, 1) S3_TERM(1, 0) S3_TERM(0, 0)
+    if constexpr (PLAIN) {
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) { S3_TERM(pl, pl) }
+    } else {
+      S3_TERM(0, 2) S3_TERM(2, 0) S3_TERM(1, 1) S3_TERM(0, 1) S3_TERM(1, 0) S3_TERM(0, 0)
+    }
 #undef S3_TERM
   };
   auto step = [&](const Frags& cur, Frags& nxt, int kc) {
@@ -260,6 +269,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split3_kernel(const pf_conv
         for (int r = 0; r < 4; ++r) v[r] = softplus20(v[r]);
       }
       v[0] *= scale_r[fn].x; v[1] *= scale_r[fn].y; v[2] *= scale_r[fn].z; v[3] *= scale_r[fn].w;
+      if constexpr (PLAIN) {
+        if (p.res) {
+          float a[4];
+          load4(reinterpret_cast<const bf16_t*>(p.res) + (long)m * p.res_ld + n, a);
+          v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3];
+        }
+        if (p.res2) {
+          float a[4];
+          load4(reinterpret_cast<const bf16_t*>(p.res2) + (long)m * p.res2_ld + n, a);
+          v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3];
+        }
+        if (p.out_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (long)m * p.y_ld + n) = make_float4(v[0], v[1], v[2], v[3]);
+        else store4(reinterpret_cast<bf16_t*>(p.y) + (long)m * p.y_ld + n, v[0], v[1], v[2], v[3]);
+      } else {
       if (p.res) {
         const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) + (long)m * p.res_ld + n);
         v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
@@ -270,20 +293,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split3_kernel(const pf_conv
       }
       if (p.out_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (long)m * p.y_ld + n) = make_float4(v[0], v[1], v[2], v[3]);
       else store_split3(reinterpret_cast<bf16_t*>(p.y) + (long)m * p.y_ld + n, p.y_bstride, v);
+      }
     }
   }
 }
 
 thread_local char g_err[200] = {0};
 
-template <int BM, int BN, int WM, int WN, int NS, bool PP = false>
+template <int BM, int BN, int WM, int WN, int NS, bool PP = false, int NP = 3, bool PLAIN = false>
 int launch(const pf_conv_params& p, hipStream_t st) {
-  constexpr int smem = NS * 3 * (BM + BN) * 64;
+  constexpr int smem = NS * NP * (BM + BN) * 64;
   static std::atomic<unsigned long long> done{0};
   int dev = 0;
   hipGetDevice(&dev);
   const unsigned long long bit = 1ull << (dev & 63);
-  auto kern = gemm_split3_kernel<BM, BN, WM, WN, NS, PP>;
+  auto kern = gemm_split3_kernel<BM, BN, WM, WN, NS, PP, NP, PLAIN>;
   if (!(done.load(std::memory_order_acquire) & bit)) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     done.fetch_or(bit, std::memory_order_release);
@@ -323,6 +347,20 @@ extern "C" int pf_gemm_split3(const pf_conv_params* p, void* stream) {
     if (small) return launch<64, 128, 2, 2, 2>(*p, st);
   const char* pp = getenv("PF_S3_PP");                    // (A/B switch; read per call)
   return (pp && pp[0] == '0') ? launch<128, 128, 4, 2, 3, false>(*p, st) : launch<128, 128, 4, 2, 3, true>(*p, st);
+}
+
+// plain bf16 linear layer through the ping-pong pipeline (see the PLAIN template parameter): x [M][x_ld] bf16, w [w_rows][Kpad] bf16
+// (packing.pack_conv), bias / scale float32, res / res2 / y bf16 (y float32 when out_f32); Cin % 64 == 0.  Tile 256 x 128, eight waves of 64 x 64.
+extern "C" int pf_gemm_bf16_pp(const pf_conv_params* p, void* stream) {
+  if (!p || !p->x || !p->w || !p->y) return PF_ERR_ARG;
+  if (p->KH != 1 || p->KW != 1 || p->stride != 1 || p->pad != 0 || p->shuffle > 1 || p->dtype != PF_DTYPE_BF16) return PF_ERR_ARG;
+  if (p->Cin <= 0 || p->Cin % 64 || p->Kpad < p->Cin || p->x_ld % 8 || p->x_ld < p->Cin || p->Kpad % 8) return PF_ERR_ARG;
+  if (p->Cout <= 0 || p->Cout % 4 || p->y_ld % 4 || p->w_rows < p->Cout || (p->res && p->res_ld % 4) || (p->res2 && p->res2_ld % 4)) return PF_ERR_ARG;
+  if ((long)p->B * p->OH * p->OW <= 0 || (long)p->B * p->OH * p->OW >= (1L << 31)) return PF_ERR_ARG;
+  pf_conv_params pd = *p;
+  pd.x_bstride = 32;                     // "planes" = consecutive 32-deep K sub-chunks of the one bf16 matrix
+  pd.w_bstride = 32;
+  return launch<256, 128, 4, 2, 3, true, 2, true>(pd, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int pf_gemm_split3_timed(const pf_conv_params* p, int iters, float* ms, void* stream) {

@@ -68,6 +68,15 @@ def _ld(t):
     return ld
 
 
+def _bf16_pp_enabled():
+    """plain bf16 linears through the split GEMM's ping-pong pipeline (pf_gemm_bf16_pp, 256 x 128 tiles): measured and NOT kept -- 0.095 /
+    0.047 / 0.118 / 0.126 ms on the ViT-L qkv / proj / fc1 / fc2 shapes against 0.086 / 0.038 / 0.108 / 0.105 for the implicit-GEMM kernels
+    (profiles/r3_bf16_pp_sweep.log): one product per fragment pair does not amortise the pipeline the way the split GEMM's six do.
+    PF_BF16_PP=1 turns it on (A/B, tests/op_checks.py conv_bf16_pp)."""
+    import os
+    return os.environ.get("PF_BF16_PP", "0") == "1"
+
+
 def _fused_wanted(B, H, W, cin, cout):
     """PF_WINO_FUSED (read per call): 0 = three-step path only, 2 = the fused kernel for every layer it supports, 1 (default) = the
     measured rule (profiles/r3_wino_fused_time.log, 1x MI355X): the fused kernel wins wherever it has at least two rounds of blocks
@@ -150,6 +159,22 @@ class HipOps:
         p.korder = pw.korder
         for t in (x4, y4, pw.w, res, res2):
             _p(t)
+        if (x4.dtype == torch.bfloat16 and pw.KH == 1 and pw.KW == 1 and stride == 1 and pad == 0 and s == 1 and not relu_in and not _direct and
+                B * H * W >= 2048 and pw.cin % 64 == 0 and pw.cin >= 512 and pw.cout >= 512 and _bf16_pp_enabled()):
+            # bf16 linear layers with many token rows (ViT blocks, DPT projections): 256 x 128 ping-pong tiles (csrc/gemm_split3.hip, PLAIN)
+            def run_pp():
+                check(_L.pf_gemm_bf16_pp(C.byref(p), _stream()), "pf_gemm_bf16_pp")
+            if _timed is None:
+                run_pp()
+                return y
+            run_pp()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(int(_timed)):
+                run_pp()
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / int(_timed)
         wino = winograd_applies(pw, B * H * W, stride, pad, act) and not _direct
         if _timed is not None and not wino:
             ms = C.c_float(0)

@@ -278,6 +278,26 @@ def conv_gemm_vitl_linear_shape(dt):      # M = 8 x 1037 rows like the ViT-L lin
     return _conv_case(dt, 1, 1, 8 * 1037, 256, 1024, 1, scale=True, res=True, seed=33)
 
 
+def conv_bf16_pp(dt):
+    """bf16 linear layers on the 256 x 128 ping-pong tiles (pf_gemm_bf16_pp, opt-in: PF_BF16_PP=1) against the torch reference AND the
+    implicit-GEMM kernel (PF_BF16_PP=0): ragged token counts, every epilogue option, in-place residual, float32 output"""
+    import os
+    worst, info = 0.0, []
+    cases = [dict(B=1, H=1, W=8 * 1037, cin=1024, cout=3072, k=1, seed=51), dict(B=1, H=1, W=2500, cin=4096, cout=1024, k=1, scale=True, res=True, inplace=True, seed=52),
+             dict(B=1, H=1, W=2049, cin=1024, cout=1024, k=1, res=True, res2=True, act="relu", seed=53), dict(B=1, H=1, W=3 * 1037, cin=1024, cout=4096, k=1, act="gelu", seed=54),
+             dict(B=2, H=37, W=41, cin=512, cout=516, k=1, out_f32=True, y_extra=24, x_extra=16, seed=55)]
+    for c in cases:
+        errs = []
+        for flag in ("1", "0"):
+            os.environ["PF_BF16_PP"] = flag
+            e, tol, _ = _conv_case(dt, c["B"], c["H"], c["W"], c["cin"], c["cout"], c["k"], **{k: v for k, v in c.items() if k not in ("B", "H", "W", "cin", "cout", "k")})
+            errs.append(e)
+        os.environ.pop("PF_BF16_PP", None)
+        worst = max(worst, errs[0])
+        info.append(f"{c['cin']}->{c['cout']} M={c['B'] * c['H'] * c['W']}: pp {errs[0]:.2e} igemm {errs[1]:.2e}")
+    return worst, _tol(dt), "; ".join(info)
+
+
 def conv_dominant_launch(dt):
     """THE dominant launch at its real size: 3x3 544->544 @ 8x392x518 (GuidedFusion Upv1, guided_fusion_model.py:85-100)
     against F.conv2d in fp32 on the same (dtype-rounded) operands."""
@@ -709,7 +729,7 @@ CHECKS = {
     "conv_big_gemm_scale_inplace": conv_big_gemm_scale_inplace, "conv_big_gemm_gelu_k1024": conv_big_gemm_gelu_k1024,
     "conv_big_transpose": conv_big_transpose,
     "conv_split_n272_res_views": conv_split_n272_res_views, "conv_split_gemm_n544_inplace": conv_split_gemm_n544_inplace,
-    "conv_gemm_vitl_linear_shape": conv_gemm_vitl_linear_shape, "conv_dominant_launch": conv_dominant_launch,
+    "conv_gemm_vitl_linear_shape": conv_gemm_vitl_linear_shape, "conv_bf16_pp": conv_bf16_pp, "conv_dominant_launch": conv_dominant_launch,
     "conv_transpose": conv_transpose, "patch_embed_tokens": patch_embed_tokens, "layernorm": layernorm,
     "vit_attention": vit_attention, "vit_attention_split": vit_attention_split, "gemm_split3": gemm_split3, "swin_ops": swin_ops, "resize_ops": resize_ops, "roi_ops": roi_ops,
     "conv_winograd": conv_winograd, "conv_winograd_fused": conv_winograd_fused, "misc_ops": misc_ops, "bins_ops": bins_ops, "bins_tail": bins_tail, "stitch_ops": stitch_ops,

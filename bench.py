@@ -238,7 +238,7 @@ def gemm_sweep(dtype, dev, only=()):
 
 def kernel_source_sha():
     h = hashlib.sha256()
-    for f in ("igemm.hip", "wino_fused.hip", "pf_common.h"):
+    for f in ("igemm.hip", "wino_fused.hip", "gemm_split3.hip", "winograd.hip", "pf_common.h"):
         with open(os.path.join(ROOT, "patchfusion_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:12]
@@ -275,7 +275,43 @@ def roofline(dtype, dev, gemm_only=False):
         pass
     direct_flops = 2.0 * B * H * W * 9 * C * C
     from patchfusion_amd import hip_ops
-    if pw.wino_up is not None and pk.winograd_applies(pw, B * H * W, 1, 1, "relu") and hip_ops._fused_wanted(B, H, W, C, C):
+    if (pw.wino_u3 is not None and pk.winograd_applies(pw, B * H * W, 1, 1, "relu") and hip_ops._split3_three_step(pw) and
+            not hip_ops._fused_wanted(B, H, W, pw)):
+        # round 3 (late): the layer runs as input transform (three bf16 planes) -> ONE batched split-precision GEMM launch over the 36 transform
+        # points -> output transform.  Dominant launch = that GEMM (gemm_split3_kernel, v_mfma_f32_16x16x32_bf16 x 6 per useful product):
+        # priced as its USEFUL float32 multiply-adds 36 * 2 * T * C * C against the f32 MFMA peak -- the roofline of the arithmetic the layer
+        # asks for -- with the executed bf16 rate against the bf16 peak beside it.
+        T = B * -(-H // 4) * -(-W // 4)
+        V3 = torch.randn(3, 36, T, C, device=dev).to(torch.bfloat16)
+        Mw = torch.empty(36 * T * C, device=dev)
+        ms = ops.gemm_planes_split3_timed(V3, pw.wino_u3, Mw.view(36, T, C), T, C, C, 5)
+        flops = 36 * 2.0 * T * C * C
+        ach = flops / (ms * 1e-3) / 1e12
+        del V3, Mw
+        ms_layer = None
+        if not gemm_only:                 # (--roofline-only = PMC passes: the GEMM launches alone)
+            x = torch.randn(B, H, W, C, device=dev)
+            y = torch.empty(B, H, W, C, device=dev)
+            ms_layer = ops.conv(x, pw, y, pad=1, act="relu", _timed=5)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r3_pmc_dominant_fp32.json")) as f:
+                j = json.load(f)
+            traffic = j["derived"]["traffic_bytes"] if j.get("kernel_source_sha") == kernel_source_sha() else None
+        except Exception:
+            traffic = None
+        return {"bound": "mfma",
+                "kernel": f"gemm_split3_kernel (6 x v_mfma_f32_16x16x32_bf16 per float32 product, f32 accumulation) as the batched transform-domain GEMM of the "
+                          f"largest layer: 36 planes x [{T} x {C}].[{C} x {C}] = 3x3 {C}->{C} @ {B}x{H}x{W} (GuidedFusion up-conv) under Winograd F(4x4,3x3)",
+                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "traffic": traffic, "winograd_m": 4,
+                "note": "achieved / peak = USEFUL float32 FLOPs of the launch over the f32 MFMA peak (157.3 TF/s); the launch executes 6x as many bf16 "
+                        "FLOPs: see executed_bf16",
+                "executed_bf16": {"tflops": round(6 * ach, 1), "peak": PEAK_TFLOPS["bf16"], "frac": round(6 * ach / PEAK_TFLOPS["bf16"], 4)},
+                "layer": None if ms_layer is None else {
+                    "what": f"whole layer = input transform (split planes) + batched GEMM + output transform/epilogue, 3x3 {C}->{C} @ {B}x{H}x{W}",
+                    "ms": round(ms_layer, 4), "transforms_ms": round(ms_layer - ms, 4), "direct_conv_flops": direct_flops,
+                    "direct_conv_tflops_equivalent": round(direct_flops / (ms_layer * 1e-3) / 1e12, 2)}}
+    if pw.wino_up is not None and pk.winograd_applies(pw, B * H * W, 1, 1, "relu") and hip_ops._fused_wanted(B, H, W, pw):
         # round 3: the layer is ONE kernel (csrc/wino_fused.hip): its own multiply-adds = 36 transform points x 2 x T x C x C with
         # T = B * ceil(H/4) * ceil(W/4) output tiles (the padding tiles of the 4x8 super-tiles are not counted), priced against the
         # f32 MFMA peak; the kernel also does both transforms and the epilogue, so kernel == layer

@@ -73,6 +73,10 @@ int pf_conv_timed(const pf_conv_params* p, int iters, float* ms, void* stream);
  * T = B * ceil(H/m) * ceil(W/m).  Input transform -> (m+2)^2 GEMMs through pf_conv -> output transform + epilogue (winograd.hip).
  * m = 2 multiplies 2.25x less than the direct convolution at ~2.5x its float32 rounding error, m = 4 4x less at ~15x. */
 int pf_conv_winograd(const pf_conv_params* p, int m, const void* U, int u_rows, int u_kpad, void* V, void* M, void* stream);
+/* The same three steps with the transform-domain GEMM in split precision (m = 4): V3 = workspace of 3 x 36 x T x Cin bf16 (the input transform
+ * writes the three planes), U3 = packing.winograd_filters_split3 ([3][36][u_rows][u_kpad] bf16), M = 36 x T x Cout float32; one batched
+ * pf_gemm_split3 launch between the transforms. */
+int pf_conv_winograd_split3(const pf_conv_params* p, const void* U3, int u_rows, int u_kpad, void* V3, void* M, void* stream);
 
 /* FUSED Winograd F(4x4, 3x3) (csrc/wino_fused.hip): the same layers in ONE kernel -- the transformed input and the transform-domain
  * products never exist in HBM.  `p` as for pf_conv_winograd (p->w is not read); `up` = the filters in MFMA fragment order

@@ -55,6 +55,7 @@ SIGNATURES = {
     "pf_pack_fusion_input": [vp, vp, vp, vp, ci, ci, ci, ci, vp],
     "pf_nhwc_to_nchw_f32": [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp],
     "pf_conv_winograd": [C.POINTER(ConvParams), ci, vp, ci, ci, vp, vp, vp],
+    "pf_conv_winograd_split3": [C.POINTER(ConvParams), vp, ci, ci, vp, vp, vp],
     "pf_gemm_split3": [C.POINTER(ConvParams), vp],
     "pf_gemm_split3_timed": [C.POINTER(ConvParams), ci, C.POINTER(cf), vp],
     "pf_gemm_bf16_pp": [C.POINTER(ConvParams), vp],

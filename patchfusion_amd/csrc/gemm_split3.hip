@@ -82,8 +82,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split3_kernel(const pf_conv
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // ---- loader: wave w moves pieces w*PPW .. +PPW-1; lane L -> row 16 q + (L >> 2), physical slot L & 3 = logical slot ^ ((row >> 1) & 3)
-  const bf16_t* __restrict__ xg = reinterpret_cast<const bf16_t*>(p.x);
-  const bf16_t* __restrict__ wg = reinterpret_cast<const bf16_t*>(p.w);
+  // batch > 1 (the transform points of a Winograd layer, csrc/winograd.hip run_split3): point blockIdx.y reads the [M][x_ld] / [w_rows][Kpad]
+  // block number blockIdx.y of every plane and writes the float32 block [M][y_ld] number blockIdx.y
+  const long bz = blockIdx.y;
+  const bf16_t* __restrict__ xg = reinterpret_cast<const bf16_t*>(p.x) + bz * (long)M * p.x_ld;
+  const bf16_t* __restrict__ wg = reinterpret_cast<const bf16_t*>(p.w) + bz * (long)p.w_rows * p.Kpad;
+  const long y_base = bz * (long)M * p.y_ld;
   const char* zero = reinterpret_cast<const char*>(s3_zero_page);
   const char* cur[PPW];
   int inc[PPW];
@@ -160,7 +164,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split3_kernel(const pf_conv
       for (int fm = 0; fm < FM; ++fm) f.x[pl][fm] = *reinterpret_cast<const uint4*>(S + x_off + pl * (BM * 64) + fm * 1024);
     }
   };
-  // six partial products, smallest first; within a term the FN*FM accumulators are independent chains
+  // six partial products, smallest first; within a term the FN*FM accumulators are independent chains.  (Skipping the channel fragments
+  // beyond Cout -- 544 = 4 x 128 + 32 -- behind a wave-uniform test was measured: 3-7 % SLOWER on every shape, the test breaks the MFMA
+  // schedule; profiles/r3_three_step_split.log vs r3aj)
   auto multiply = [&](const Frags& f) {
     if (S3_DBG(2)) return;
 #define S3_TERM(PW, PX)                                                                                                      \
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split3_kernel(const pf_conv
         const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res2) + (long)m * p.res2_ld + n);
         v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
       }
-      if (p.out_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (long)m * p.y_ld + n) = make_float4(v[0], v[1], v[2], v[3]);
+      if (p.out_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + y_base + (long)m * p.y_ld + n) = make_float4(v[0], v[1], v[2], v[3]);
       else store_split3(reinterpret_cast<bf16_t*>(p.y) + (long)m * p.y_ld + n, p.y_bstride, v);
       }
     }
@@ -314,7 +320,7 @@ int launch(const pf_conv_params& p, hipStream_t st) {
   }
   const long M = (long)p.B * p.OH * p.OW;
   const long tiles = ((M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64 * WM * WN), smem, st, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)(p.batch > 1 ? p.batch : 1)), dim3(64 * WM * WN), smem, st, p);
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_LAUNCH;
 }
 
@@ -336,6 +342,7 @@ extern "C" int pf_gemm_split3(const pf_conv_params* p, void* stream) {
   else if ((p->res && p->res_ld % 4) || (p->res2 && p->res2_ld % 4)) e = "residual ld must be a multiple of 4";
   else if ((long)p->B * p->OH * p->OW <= 0 || (long)p->B * p->OH * p->OW >= (1L << 31)) e = "bad token count";
   else if (p->x_bstride <= 0 || p->w_bstride <= 0 || (!p->out_f32 && p->y_bstride <= 0)) e = "plane strides missing";
+  else if (p->batch > 1 && (!p->out_f32 || p->bias || p->scale || p->res || p->res2 || p->batch > 65535)) e = "batched planes: float32 output, no epilogue";
   if (e) return PF_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   // tile: 128 x 128 (eight waves, one block per CU, ping-pong) unless the token x channel grid does not fill the chip once; PF_S3_TILE_NOW forces

@@ -54,7 +54,8 @@ template <> struct Wino<4> {
 // one thread = one tile x 4 channels: (m+2)^2 16-byte loads (zero outside the image = the conv's padding), B^T d B in registers,
 // (m+2)^2 16-byte stores into the planes of V.  Consecutive lanes take consecutive channel groups: every load / store of a wave is
 // a contiguous 1 KiB run of one pixel / one V row.
-template <int MT>
+// SPLIT: V is written as the three bf16 planes of the split-precision GEMM (csrc/gemm_split3.hip): [3][(m+2)^2][T][C] bf16
+template <int MT, bool SPLIT = false>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int x_ld, int B, int H, int W, int C, int relu_in,
                                                          float* __restrict__ V, int TH, int TW) {
   constexpr int A = MT + 2;
@@ -101,12 +102,20 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     }
   }
   const size_t plane = (size_t)T * C;
-  float* o = V + (size_t)tile * C + c4 * 4;
+  if constexpr (SPLIT) {
+    bf16_t* o = reinterpret_cast<bf16_t*>(V) + (size_t)tile * C + c4 * 4;
 #pragma unroll
-  for (int i = 0; i < A; ++i)
+    for (int i = 0; i < A; ++i)
 #pragma unroll
-    for (int j = 0; j < A; ++j)
-      *reinterpret_cast<float4*>(o + (size_t)(i * A + j) * plane) = make_float4(d[i][j][0], d[i][j][1], d[i][j][2], d[i][j][3]);
+      for (int j = 0; j < A; ++j) store_split3(o + (size_t)(i * A + j) * plane, (long)(A * A) * (long)plane, d[i][j]);
+  } else {
+    float* o = V + (size_t)tile * C + c4 * 4;
+#pragma unroll
+    for (int i = 0; i < A; ++i)
+#pragma unroll
+      for (int j = 0; j < A; ++j)
+        *reinterpret_cast<float4*>(o + (size_t)(i * A + j) * plane) = make_float4(d[i][j][0], d[i][j][1], d[i][j][2], d[i][j][3]);
+  }
 }
 
 // one thread = one tile x 4 output channels: (m+2)^2 16-byte loads from the planes of M, A^T m A, then the conv epilogue in the order of
@@ -210,7 +219,44 @@ int run(const pf_conv_params* p, const float* U, int u_rows, int u_kpad, float* 
   return launch_ok();
 }
 
+// F(4x4,3x3) with the transform-domain GEMM in split precision: V is written as three bf16 planes, U3 = the three planes of G g G^T
+// ([3][36][u_rows][u_kpad] bf16, packing.winograd_filters_split3), ONE batched pf_gemm_split3 launch (plane = blockIdx.y), M float32.
+int run_split3(const pf_conv_params* p, const void* U3, int u_rows, int u_kpad, void* V3, float* M, hipStream_t st) {
+  constexpr int MT = 4, A = 6;
+  const int TH = (p->H + MT - 1) / MT, TW = (p->W + MT - 1) / MT;
+  const long T = (long)p->B * TH * TW;
+  if (T > 0x7fffffffL) return PF_ERR_ARG;
+  const long nin = T * (p->Cin / 4), nout = T * (p->Cout / 4);
+  hipLaunchKernelGGL((wino_input_kernel<MT, true>), dim3((unsigned)((nin + 255) / 256)), dim3(256), 0, st, static_cast<const float*>(p->x), p->x_ld,
+                     p->B, p->H, p->W, p->Cin, p->relu_in, static_cast<float*>(V3), TH, TW);
+  if (launch_ok() != PF_OK) return PF_ERR_LAUNCH;
+  pf_conv_params q = {};
+  q.x_ld = p->Cin; q.B = 1; q.H = 1; q.W = (int)T; q.Cin = p->Cin;
+  q.w_rows = u_rows; q.Kpad = u_kpad;
+  q.y_ld = p->Cout; q.OH = 1; q.OW = (int)T; q.Cout = p->Cout;
+  q.KH = q.KW = 1; q.stride = 1; q.pad = 0; q.act = PF_ACT_NONE; q.shuffle = 1; q.dtype = PF_DTYPE_BF16; q.out_f32 = 1;
+  q.x = V3; q.w = U3; q.y = M;
+  q.batch = A * A;                                      // transform points: x / w / y advance by one [T][Cin] / [rows][Kpad] / [T][Cout] block each
+  q.x_bstride = (long)A * A * T * p->Cin;               // h / m / l plane strides
+  q.w_bstride = (long)A * A * u_rows * u_kpad;
+  const int rc = pf_gemm_split3(&q, st);
+  if (rc != PF_OK) return rc;
+  hipLaunchKernelGGL(wino_output_kernel<MT>, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, M, p->Cout, p->bias,
+                     p->act == PF_ACT_RELU ? 1 : 0, static_cast<const float*>(p->res), p->res_ld, static_cast<const float*>(p->res2),
+                     p->res2_ld, static_cast<float*>(p->y), p->y_ld, p->B, p->H, p->W, TH, TW);
+  return launch_ok();
+}
+
 }  // namespace
+
+extern "C" int pf_conv_winograd_split3(const pf_conv_params* p, const void* U3, int u_rows, int u_kpad, void* V3, void* M, void* stream) {
+  if (!p || !U3 || !V3 || !M || !p->x || !p->y) return PF_ERR_ARG;
+  if (p->dtype != PF_DTYPE_F32 || p->KH != 3 || p->KW != 3 || p->stride != 1 || p->pad != 1 || p->shuffle > 1 || p->scale) return PF_ERR_ARG;
+  if (p->OH != p->H || p->OW != p->W || p->Cin % 32 || p->Cout % 8 || p->Cin <= 0 || p->Cout <= 0) return PF_ERR_ARG;
+  if (p->act != PF_ACT_NONE && p->act != PF_ACT_RELU) return PF_ERR_ARG;
+  if (u_rows < p->Cout || u_kpad < p->Cin || u_kpad % 32) return PF_ERR_ARG;
+  return run_split3(p, U3, u_rows, u_kpad, V3, static_cast<float*>(M), ST(stream));
+}
 
 extern "C" int pf_conv_winograd(const pf_conv_params* p, int m, const void* U, int u_rows, int u_kpad, void* V, void* M, void* stream) {
   if (!p || !U || !V || !M || !p->x || !p->y) return PF_ERR_ARG;

@@ -77,11 +77,19 @@ def _bf16_pp_enabled():
     return os.environ.get("PF_BF16_PP", "0") == "1"
 
 
-def _fused_wanted(B, H, W, cin, cout):
-    """PF_WINO_FUSED (read per call): 0 = three-step path only, 2 = the fused kernel for every layer it supports, 1 (default) = the
-    measured rule (profiles/r3_wino_fused_time.log, 1x MI355X): the fused kernel wins wherever it has at least two rounds of blocks
-    and the layer is not 768+ -> 768+ channels (there the batched GEMM's 128x64 tiles re-use the filters better: 0.95-0.98x), i.e.
-    1.01x (544->544 @ 8x392x518) ... 1.2-1.7x (256/512 -> 128/256 channels) ... 2.0-2.4x (-> 32 channels) of the three-step time."""
+def _split3_three_step(pw):
+    """does the three-step form of this layer run its GEMM in split precision? (filters packed as three planes and PF_WINO_SPLIT3 != 0)"""
+    import os
+    return pw.wino_u3 is not None and os.environ.get("PF_WINO_SPLIT3", "1") != "0"
+
+
+def _fused_wanted(B, H, W, pw):
+    """Fused Winograd kernel (csrc/wino_fused.hip) or the three-step form for this call?  PF_WINO_FUSED (read per call): 0 = never fused,
+    2 = fused wherever supported, 1 (default) = the measured rule (profiles/r3_wino_fused_layers.log, r3_three_step_split.log; 1x MI355X):
+    the fused kernel needs at least two rounds of blocks, and it loses to the three-step form on layers with MANY OUTPUT CHANNELS -- each of
+    the ceil(Cout/64) channel blocks repeats the input transform, while the batched GEMM of the three-step form runs near its peak there:
+    with the split-precision GEMM from 512 output channels on (544->544 @ 8x392x518: 20.7 vs 22.5 ms; 768->768 @ 8x224x296: 10.3 vs 13.5),
+    with the f32 GEMM only at 768+ -> 768+ (13.0 vs 13.5).  Below that the fused kernel wins 1.1x (768->256) ... 2.4x (-> 32 channels)."""
     import os
     mode = os.environ.get("PF_WINO_FUSED", "1")
     if mode == "0":
@@ -90,7 +98,13 @@ def _fused_wanted(B, H, W, cin, cout):
         return True
     th, tw = -(-H // 4), -(-W // 4)
     nsuper = B * min(-(-th // 4) * -(-tw // 8), -(-th // 8) * -(-tw // 4))
-    return nsuper * -(-cout // 64) >= 512 and not (cin >= 768 and cout >= 768)
+    if pw.wino_u is None:
+        many_out = False                                    # fused-only layer: the alternative is the direct kernel
+    elif _split3_three_step(pw):
+        many_out = pw.cout >= 512
+    else:
+        many_out = pw.cin >= 768 and pw.cout >= 768
+    return nsuper * -(-pw.cout // 64) >= 512 and not many_out
 
 
 _WS = {}
@@ -180,7 +194,7 @@ class HipOps:
             ms = C.c_float(0)
             check(_L.pf_conv_timed(C.byref(p), int(_timed), C.byref(ms), _stream()), "pf_conv_timed")
             return ms.value
-        if wino and pw.wino_up is not None and _fused_wanted(B, H, W, pw.cin, pw.cout) and _L.pf_conv_winograd_fused_supported(C.byref(p)):
+        if wino and pw.wino_up is not None and _fused_wanted(B, H, W, pw) and _L.pf_conv_winograd_fused_supported(C.byref(p)):
             # fused F(4x4,3x3): one kernel, no V / M workspaces (csrc/wino_fused.hip)
             assert y4.dtype == torch.float32 and (res is None or res.dtype == torch.float32) and (res2 is None or res2.dtype == torch.float32)
             _p(pw.wino_up)
@@ -204,9 +218,15 @@ class HipOps:
             T = B * -(-H // m) * -(-W // m)
             a2 = (m + 2) ** 2
             assert y4.dtype == torch.float32 and (res is None or res.dtype == torch.float32) and (res2 is None or res2.dtype == torch.float32)
-            V, Mw = _workspace(x4.device, a2 * T * pw.cin, a2 * T * pw.cout)
+            split = m == 4 and _split3_three_step(pw)
+            # (split: V holds three bf16 planes = 6 bytes per element instead of 4)
+            V, Mw = _workspace(x4.device, (a2 * T * pw.cin * 3 + 1) // 2 if split else a2 * T * pw.cin, a2 * T * pw.cout)
 
             def run():
+                if split:
+                    check(_L.pf_conv_winograd_split3(C.byref(p), _p(pw.wino_u3), pw.wino_u3.shape[2], pw.wino_u3.shape[3], _p(V), _p(Mw), _stream()),
+                          "pf_conv_winograd_split3")
+                    return
                 check(_L.pf_conv_winograd(C.byref(p), m, _p(pw.wino_u), pw.wino_u.shape[1], pw.wino_u.shape[2], _p(V), _p(Mw), _stream()),
                       "pf_conv_winograd")
             if _timed is None:
@@ -222,6 +242,24 @@ class HipOps:
             return e0.elapsed_time(e1) / int(_timed)
         check(_L.pf_conv(C.byref(p), _stream()), "pf_conv")
         return y
+
+    @staticmethod
+    def gemm_planes_split3_timed(V3, U3, Mw, T, cin, cout, iters):
+        """time the batched split-precision GEMM launch of a three-step Winograd layer alone (bench.py roofline), exactly as
+        csrc/winograd.hip run_split3 issues it: V3 bf16 [3, 36, T, cin], U3 bf16 [3, 36, rows, Kpad], Mw float32 [36, T, cout]"""
+        assert V3.dtype == U3.dtype == torch.bfloat16 and Mw.dtype == torch.float32 and tuple(V3.shape) == (3, 36, T, cin) and U3.shape[:2] == (3, 36)
+        p = ConvParams()
+        p.x, p.x_ld, p.B, p.H, p.W, p.Cin = V3.data_ptr(), cin, 1, 1, T, cin
+        p.w, p.w_rows, p.Kpad = U3.data_ptr(), U3.shape[2], U3.shape[3]
+        p.y, p.y_ld, p.OH, p.OW, p.Cout = Mw.data_ptr(), cout, 1, T, cout
+        p.KH = p.KW = p.stride = 1
+        p.act, p.shuffle, p.dtype, p.out_f32, p.batch = 0, 1, 1, 1, 36
+        p.x_bstride, p.w_bstride = V3.stride(0), U3.stride(0)
+        for t in (V3, U3, Mw):
+            _p(t)
+        ms = C.c_float(0)
+        check(_L.pf_gemm_split3_timed(C.byref(p), int(iters), C.byref(ms), _stream()), "pf_gemm_split3_timed")
+        return ms.value
 
     @staticmethod
     def gemm_planes_timed(V, U, Mw, planes, T, cin, cout, iters):

@@ -34,6 +34,7 @@ class PackedConv:
     wino_m: int = 0                 # Winograd F(m x m, 3 x 3) output tile (2 | 4), 0 = direct kernel only
     wino_u: Optional[torch.Tensor] = None   # [(m+2)^2, rows, Kpad1] float32: G g G^T, each plane packed like a 1x1 weight
     wino_up: Optional[torch.Tensor] = None  # m = 4 only: the same filters in the fragment order of the fused kernel (winograd_filters_fused)
+    wino_u3: Optional[torch.Tensor] = None  # m = 4 only: wino_u as the three bf16 planes of the split-precision GEMM, [3, 36, rows, Kpad1]
 
     def to(self, device):
         self.w = self.w.to(device)
@@ -41,6 +42,8 @@ class PackedConv:
             self.wino_u = self.wino_u.to(device)
         if self.wino_up is not None:
             self.wino_up = self.wino_up.to(device)
+        if self.wino_u3 is not None:
+            self.wino_u3 = self.wino_u3.to(device)
         if self.bias is not None:
             self.bias = self.bias.to(device)
         if self.scale is not None:
@@ -82,6 +85,13 @@ def winograd_eligible(cout_store, cin_total, KH, KW, dtype):
     """layers worth the three-step path: float32, 3x3, whole 128-byte channel chunks on both sides, K = Cin of at least four chunks
     (the 8 / 32 / 64-channel 3x3 layers stay on the direct kernel)"""
     return dtype == torch.float32 and KH == 3 and KW == 3 and cin_total % 32 == 0 and cin_total >= 128 and cout_store % 32 == 0
+
+
+def winograd_split3_enabled():
+    """three-step Winograd layers: run the transform-domain GEMM in split precision (pf_conv_winograd_split3)?  PF_WINO_SPLIT3=0 disables
+    (read at packing time: the three-plane filters are only built when enabled)"""
+    import os
+    return os.environ.get("PF_WINO_SPLIT3", "1") != "0"
 
 
 def winograd_fused_only_eligible(cout_store, cin_total, KH, KW, dtype):
@@ -183,9 +193,10 @@ def pack_conv(weight, bias=None, *, dtype, cin_map=None, cin_total=None, scale=N
     wm = winograd_mode() if (scale is None and winograd_eligible(cout_store, cin_total, KH, KW, dtype)) else 0
     wu = winograd_filters(wk, wm) if wm else None
     wup = winograd_filters_fused(wk) if wm == 4 else None
+    wu3 = torch.stack(split3(wu)).contiguous() if (wm == 4 and winograd_split3_enabled()) else None
     if wm == 0 and scale is None and winograd_fused_only_eligible(cout_store, cin_total, KH, KW, dtype):
         wm, wup = 4, winograd_filters_fused(wk)                   # fused kernel only (wino_u stays None: no three-step form)
-    return PackedConv(wp.to(dtype).contiguous(), bp, sp, KH, KW, cin_total, cout_store, cout, korder=korder, wino_m=wm, wino_u=wu, wino_up=wup)
+    return PackedConv(wp.to(dtype).contiguous(), bp, sp, KH, KW, cin_total, cout_store, cout, korder=korder, wino_m=wm, wino_u=wu, wino_up=wup, wino_u3=wu3)
 
 
 def split3(x):

@@ -70,11 +70,11 @@ def work(name, a, k):
         fl = 2.0 * opix * pw.cin * pw.KH * pw.KW * pw.cout
         wino = winograd_applies(pw, x4.shape[0] * x4.shape[1] * x4.shape[2], k.get("stride", 1), k.get("pad", 0), k.get("act"))
         from patchfusion_amd import hip_ops
-        fused = wino and pw.wino_up is not None and hip_ops._fused_wanted(x4.shape[0], x4.shape[1], x4.shape[2], pw.cin, pw.cout)
+        fused = wino and pw.wino_up is not None and hip_ops._fused_wanted(x4.shape[0], x4.shape[1], x4.shape[2], pw)
         tag = ""
         if wino and (fused or pw.wino_u is not None):
             tag = (f" [winograd F{pw.wino_m} FUSED kernel, rate = direct-conv FLOPs / time]" if fused else
-                   f" [winograd F{pw.wino_m}: 3 steps, rate = direct-conv FLOPs / time]")
+                   f" [winograd F{pw.wino_m}: 3 steps{', split-precision GEMM' if hip_ops._split3_three_step(pw) else ''}, rate = direct-conv FLOPs / time]")
         return "flop", fl, f"{tuple(x4.shape[:3])} {pw.cin}->{pw.cout} k{pw.KH} s{k.get('stride', 1)}" + (" convT" if s > 1 else "") + tag
     if name == "conv_split3":
         x3, pw, y = a[0], a[1], a[2]

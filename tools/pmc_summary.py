@@ -71,7 +71,7 @@ def main():
     if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
         der["traffic_bytes"] = der["hbm_read_bytes_corrected_x2"] + der["hbm_write_bytes"]
     h = hashlib.sha256()
-    for f in ("igemm.hip", "wino_fused.hip", "pf_common.h"):         # == bench.py kernel_source_sha()
+    for f in ("igemm.hip", "wino_fused.hip", "gemm_split3.hip", "winograd.hip", "pf_common.h"):         # == bench.py kernel_source_sha()
         h.update(open(os.path.join(ROOT, "patchfusion_amd", "csrc", f), "rb").read())
     wm = 0
     if dtype == "fp32":

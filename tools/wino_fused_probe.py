@@ -110,8 +110,12 @@ def timing(only):
         T = B * -(-H // 4) * -(-W // 4)
         fl_w, fl_d = 36 * 2.0 * T * cin * cout, 2.0 * B * H * W * 9 * cin * cout
         os.environ["PF_WINO_FUSED"] = "0"
+        os.environ["PF_WINO_SPLIT3"] = "0"
         ms3 = ops.conv(x, pw, y, pad=1, act="relu", _timed=3)
-        line = f"{name:14s} B{B} {H}x{W} {cin}->{cout}: three-step {ms3:8.3f} ms ({fl_d / ms3 / 1e9:6.1f} TF/s direct-eq) | fused"
+        os.environ["PF_WINO_SPLIT3"] = "1"
+        ms3s = ops.conv(x, pw, y, pad=1, act="relu", _timed=3)
+        line = (f"{name:14s} B{B} {H}x{W} {cin}->{cout}: three-step {ms3:8.3f} ms ({fl_d / ms3 / 1e9:6.1f} TF/s direct-eq), with the split-precision "
+                f"GEMM {ms3s:8.3f} ms | fused")
         os.environ["PF_WINO_FUSED"] = "2"
         best = None
         for gs, shp in ((1, 0), (4, 0), (8, 0), (16, 0), (64, 0), (8, 8), (8, 4)):

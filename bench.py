@@ -159,13 +159,15 @@ def main():
         out["roofline"] = roofline(args.dtype, dev)
         log(f"roofline: {out['roofline']}")
     if N == 1 and args.dtype == "fp32" and not args.no_secondary and split3_on():
-        # the same pass with every GEMM on the float32 MFMA (PF_LINEAR_SPLIT3=0): the number to quote if split-precision linears are not
+        # the same pass with every GEMM on the float32 MFMA (PF_LINEAR_SPLIT3=0 PF_WINO_SPLIT3=0): the number to quote if split-precision linears are not
         # accepted as "float32", and the measured distance between the two float32 evaluations
         os.environ["PF_LINEAR_SPLIT3"] = "0"
+        os.environ["PF_WINO_SPLIT3"] = "0"
         try:
             dt3, depth3 = run_mode("fp32")
         finally:
             os.environ.pop("PF_LINEAR_SPLIT3", None)
+            os.environ.pop("PF_WINO_SPLIT3", None)
         d3 = (depth3 - depth).abs()
         out["f32_mfma_only"] = {"value": round(P * args.steps / dt3, 3), "unit": "patches/s", "ms_per_step": round(dt3 / args.steps * 1e3, 3),
                                 "precision": PRECISION_F32[False],
@@ -194,9 +196,10 @@ def main():
 
 
 PRECISION_F32 = {
-    True: "float32 storage; convolutions and attention on the f32 MFMA; the ViT block linears as split-precision GEMMs (each f32 operand "
-          "= three bf16 planes, six partial products on the bf16 MFMA, f32 accumulation: error vs float64 <= the f32 MFMA kernel's, "
-          "tests/op_checks.py gemm_split3; PF_LINEAR_SPLIT3=0 -> f32_mfma_only)",
+    True: "float32 storage; convolutions and attention on the f32 MFMA, except the two GEMM families that run in split precision: the ViT block "
+          "linears and the transform-domain GEMM of the Winograd layers with >= 512 output channels (each f32 operand = three bf16 planes, six "
+          "partial products on the bf16 MFMA, f32 accumulation: error vs float64 <= the f32 MFMA kernel's, tests/op_checks.py gemm_split3; "
+          "PF_LINEAR_SPLIT3=0 PF_WINO_SPLIT3=0 -> f32_mfma_only)",
     False: "float32 storage + f32 MFMA everywhere (exact mode = the reference's precision)"}
 
 

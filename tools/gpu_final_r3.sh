@@ -11,7 +11,7 @@ for dt in fp32 bf16; do
   ( timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/r3f_pmc_${dt}_b -o p -- $P ) > $O/r3f_pmc_${dt}_b.log 2>&1
   ( timeout 200 rocprofv3 --pmc WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM --kernel-trace --output-format csv -d $O/r3f_pmc_${dt}_c -o p -- $P ) > $O/r3f_pmc_${dt}_c.log 2>&1
 done
-python tools/pmc_summary.py fp32 wino_fused_kernel $O/r3_pmc_dominant_fp32.json $O/r3f_pmc_fp32_a $O/r3f_pmc_fp32_b $O/r3f_pmc_fp32_c > $O/r3f_pmc_fp32_summary.log 2>&1
+python tools/pmc_summary.py fp32 gemm_split3_kernel $O/r3_pmc_dominant_fp32.json $O/r3f_pmc_fp32_a $O/r3f_pmc_fp32_b $O/r3f_pmc_fp32_c > $O/r3f_pmc_fp32_summary.log 2>&1
 python tools/pmc_summary.py bf16 conv3x3_halo_kernel $O/r3_pmc_dominant_bf16.json $O/r3f_pmc_bf16_a $O/r3f_pmc_bf16_b $O/r3f_pmc_bf16_c > $O/r3f_pmc_bf16_summary.log 2>&1
 cp $O/r3_pmc_dominant_fp32.json $O/r3_pmc_dominant_bf16.json profiles/ 2>/dev/null
 rm -f $O/r3f_pmc_*/p_kernel_trace.csv

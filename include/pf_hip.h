@@ -105,6 +105,10 @@ int pf_gemm_bf16_pp(const pf_conv_params* p, void* stream);
 int pf_layernorm_split3(const float* x, int x_ld, void* y3, int y_ld, long plane, const float* g, const float* b, float eps, long rows,
                         int D, void* stream);
 int pf_vit_attention_qkv_split3(const void* qkv, void* out3, long plane, int B, int S, int Hh, void* stream);
+/* The same attention entirely in split precision: qkv3 = the QKV GEMM's output as three bf16 planes [3][B*S][3*Hh*64] (plane stride plane_in
+ * elements), out3 = three bf16 planes [3][B*S][Hh*64] (plane_out); S^T = K.Q^T and O^T = V^T.P^T as six bf16 partial products each with float32
+ * accumulation, float32 softmax with the probabilities split in registers (csrc/vit.hip vit_attention_split3_kernel; attention.py:53-60). */
+int pf_vit_attention_split3(const void* qkv3, long plane_in, void* out3, long plane_out, int B, int S, int Hh, void* stream);
 /* float32 [rows][x_ld] -> three bf16 planes [3][rows][y_ld], plane stride `plane` elements (the split producers fuse into their stores) */
 int pf_split3(const float* x, int x_ld, void* y, int y_ld, long plane, long rows, int cols, void* stream);
 

@@ -77,20 +77,22 @@ __device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, flo
   *reinterpret_cast<uint2*>(p) = r;
 }
 
-// split-precision ("f32x3") producers, csrc/gemm_split3.hip: x = h + m + l in three bf16 planes `plane` elements apart
+// split-precision ("f32x3") producers, csrc/gemm_split3.hip: x = h + m + l in three bf16 planes.
+// Two floats -> their three packed bf16x2 words, on v_cvt_pk_bf16_f32 (round to nearest even = f2bf for finite values): 11 instructions per pair
+__device__ __forceinline__ void split3_pair(float a, float b, uint32_t& h, uint32_t& m, uint32_t& l) {
+#pragma clang fp contract(off)      // a - h must subtract from the ROUNDED value a, not fuse with the multiply that produced it
+  h = cvt_pk_bf16(a, b);
+  const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+  m = cvt_pk_bf16(ra, rb);
+  l = cvt_pk_bf16(ra - __uint_as_float(m << 16), rb - __uint_as_float(m & 0xffff0000u));
+}
 __device__ __forceinline__ void store_split3(bf16_t* y, long plane, const float (&v)[4]) {
-#pragma clang fp contract(off)      // v - h must subtract the ROUNDED value v, not fuse with the multiply that produced it
-  uint32_t h[4], m[4], l[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    h[i] = f2bf(v[i]);
-    const float r1 = v[i] - bf2f((bf16_t)h[i]);
-    m[i] = f2bf(r1);
-    l[i] = f2bf(r1 - bf2f((bf16_t)m[i]));
-  }
-  *reinterpret_cast<uint2*>(y) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-  *reinterpret_cast<uint2*>(y + plane) = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
-  *reinterpret_cast<uint2*>(y + 2 * plane) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+  uint32_t h0, m0, l0, h1, m1, l1;
+  split3_pair(v[0], v[1], h0, m0, l0);
+  split3_pair(v[2], v[3], h1, m1, l1);
+  *reinterpret_cast<uint2*>(y) = make_uint2(h0, h1);
+  *reinterpret_cast<uint2*>(y + plane) = make_uint2(m0, m1);
+  *reinterpret_cast<uint2*>(y + 2 * plane) = make_uint2(l0, l1);
 }
 
 __device__ __forceinline__ void load4(const float* p, float (&v)[4]) {

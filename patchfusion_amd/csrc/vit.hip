@@ -723,6 +723,211 @@ __global__ __launch_bounds__(256, QG == 1 ? 3 : 2) void vit_attention_qkv_f32_ke
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// float32-grade ViT attention on the bf16 matrix cores (split precision, csrc/gemm_split3.hip): q, k, v arrive as THREE bf16 planes each
+// (the QKV GEMM writes them: x = h + m + l exactly), S^T = K.Q^T and O^T = V^T.P^T are evaluated as the six leading partial products on
+// v_mfma_f32_16x16x32_bf16 with float32 accumulation, and the softmax probabilities are split in registers.  Against the f32-MFMA kernel
+// above the matrix work is 2.67x faster AND no longer shares its issue port with the softmax VALU work (the f32 MFMA does).
+//
+// Block = 4 waves x 16 queries, KV tiles of 64 keys, single LDS stage of 48 KB (three blocks per CU):
+//   Ks[p][key][64 d]   bf16, 128-byte rows, 16-byte slot s of row key at slot s ^ (key & 7)
+//   Vs[p][d][64 keys]  bf16, transposed while staging; inside each 32-key block key 16 a + 4 g + t sits at position 8 g + 4 a + t, so that
+//                      the eight keys a lane holds of P (two accumulator quads: keys 4 g + t of two 16-key fragments) are ONE 16-byte read
+//                      of V^T; 16-byte slot s of row d at slot s ^ (d & 7)
+// S^T fragment kf (16 keys): A = K rows (lane (r = key, g): d = 32 kh + 8 g ..), B = Q (lane (r = query, g): same d) -> lane (query r, g)
+// holds keys 16 kf + 4 g + e.  O^T fragment df (16 d): A = V^T rows (lane (r = d, g): the eight permuted keys of block kk), B = P.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 3) void vit_attention_split3_kernel(const bf16_t* __restrict__ qkv3, long plane_in, bf16_t* __restrict__ out3,
+                                                                      long plane_out, int B, int S, int Hh, float qscale) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * 3 * 64 * 128];
+  char* Ks = lds;
+  char* Vs = lds + 3 * 64 * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.y, b = bh / Hh, h = bh % Hh;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const bool has_q = q0 < S;
+  const int D = Hh * 64;
+  const long rs = 3L * D;
+  const bf16_t* base = qkv3 + (long)b * S * rs + h * 64;            // + plane * plane_in + s * rs (+ D for K, + 2 D for V)
+
+  uint4 qf[3][2];
+  {
+    const int qi = min(q0 + r, S - 1);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) qf[pl][kh] = *reinterpret_cast<const uint4*>(base + pl * plane_in + (long)qi * rs + 32 * kh + 8 * g);
+  }
+  f32x4 o[4];
+#pragma unroll
+  for (int fd = 0; fd < 4; ++fd) o[fd] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  const int ntiles = (S + 63) / 64;
+
+  // staging roles.  K: item (plane, key, slot): 3 x 64 x 8 = 1536 sixteen-byte items, 6 per thread.  V: item (plane, key pair, slot of 8 d):
+  // 3 x 32 x 8 = 768, 3 per thread: two 16-byte loads (keys 2 j, 2 j + 1), eight 4-byte transposing stores (positions of a key pair are adjacent)
+  uint4 kreg[6], vreg[3][2];
+  // per-thread source rows, advanced by one tile per iteration (masks only in the last tile: wave-uniform branch)
+  const bf16_t* kptr[6];
+  const bf16_t* vptr[3];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int it = tid + 256 * i;
+    kptr[i] = base + (it >> 9) * plane_in + (long)((it >> 3) & 63) * rs + D + 8 * (it & 7);
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int it = tid + 256 * i;
+    vptr[i] = base + (it >> 8) * plane_in + (long)(2 * ((it >> 3) & 31)) * rs + 2 * D + 8 * (it & 7);
+  }
+  const long tile_step = 64 * rs;
+  auto gload = [&](int kt) {
+    if (kt + 1 < ntiles) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) kreg[i] = *reinterpret_cast<const uint4*>(kptr[i]);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        vreg[i][0] = *reinterpret_cast<const uint4*>(vptr[i]);
+        vreg[i][1] = *reinterpret_cast<const uint4*>(vptr[i] + rs);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int kg = kt * 64 + (((tid + 256 * i) >> 3) & 63);
+        kreg[i] = make_uint4(0, 0, 0, 0);
+        if (kg < S) kreg[i] = *reinterpret_cast<const uint4*>(kptr[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int kg = kt * 64 + 2 * (((tid + 256 * i) >> 3) & 31);
+        vreg[i][0] = vreg[i][1] = make_uint4(0, 0, 0, 0);
+        if (kg < S) vreg[i][0] = *reinterpret_cast<const uint4*>(vptr[i]);
+        if (kg + 1 < S) vreg[i][1] = *reinterpret_cast<const uint4*>(vptr[i] + rs);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) kptr[i] += tile_step;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) vptr[i] += tile_step;
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int it = tid + 256 * i;
+      const int slot = it & 7, key = (it >> 3) & 63, pl = it >> 9;
+      *reinterpret_cast<uint4*>(Ks + (pl * 64 + key) * 128 + ((slot ^ (key & 7)) << 4)) = kreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int it = tid + 256 * i;
+      const int slot = it & 7, kp = (it >> 3) & 31, pl = it >> 8;
+      const int key = 2 * kp;                                           // even key of the pair: key = 32 kk + 16 a + 4 gg + t, t even
+      const int kk = key >> 5, a = (key >> 4) & 1, gg = (key >> 2) & 3, t = key & 3;
+      const int pos = 32 * kk + 8 * gg + 4 * a + t;                      // position inside the row (bf16 units), even
+      const uint32_t w0[4] = {vreg[i][0].x, vreg[i][0].y, vreg[i][0].z, vreg[i][0].w};
+      const uint32_t w1[4] = {vreg[i][1].x, vreg[i][1].y, vreg[i][1].z, vreg[i][1].w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int d = 8 * slot + e;
+        const uint32_t lo = (e & 1) ? (w0[e >> 1] >> 16) : (w0[e >> 1] & 0xffffu);
+        const uint32_t hi = (e & 1) ? (w1[e >> 1] >> 16) : (w1[e >> 1] & 0xffffu);
+        *reinterpret_cast<uint32_t*>(Vs + (pl * 64 + d) * 128 + (((pos >> 3) ^ (d & 7)) << 4) + (pos & 7) * 2) = lo | (hi << 16);
+      }
+    }
+  };
+
+  for (int kt = 0; kt < ntiles; ++kt) {
+    gload(kt);                              // (no register prefetch across the tile: 48 registers; three resident blocks per CU hide the latency)
+    __syncthreads();                        // every wave is done with the previous tile
+    lstore();
+    __syncthreads();
+    if (!has_q) continue;
+    // ---- S^T = K . Q^T : four 16-key fragments, six terms x two 32-deep halves each
+    f32x4 sacc[4];
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf) sacc[kf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf) {
+      uint4 kfr[3][2];
+      const int key = 16 * kf + r;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) kfr[pl][kh] = *reinterpret_cast<const uint4*>(Ks + (pl * 64 + key) * 128 + (((4 * kh + g) ^ (key & 7)) << 4));
+#define AT_TERM(PK, PQ)                                                                                                                   \
+  _Pragma("unroll") for (int kh = 0; kh < 2; ++kh) sacc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                   \
+      __builtin_bit_cast(bf16x8, kfr[PK][kh]), __builtin_bit_cast(bf16x8, qf[PQ][kh]), sacc[kf], 0, 0, 0);
+      AT_TERM(0, 2) AT_TERM(2, 0) AT_TERM(1, 1) AT_TERM(0, 1) AT_TERM(1, 0) AT_TERM(0, 0)
+#undef AT_TERM
+    }
+    // ---- online softmax on base-2 logits (lane (query r, g) holds keys 16 kf + 4 g + e)
+    float mx = -INFINITY;
+    const bool last = kt + 1 == ntiles;
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = sacc[kf][e] * qscale;
+        if (last && kt * 64 + 16 * kf + 4 * g + e >= S) v = -INFINITY;
+        sacc[kf][e] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+    uint4 pf[3][2];                        // P as three bf16 planes, key block kk: elements t < 4 = fragment 2 kk, t >= 4 = fragment 2 kk + 1
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      float pv[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        pv[t] = __builtin_amdgcn_exp2f(sacc[2 * kk + (t >> 2)][t & 3] - m_new);
+        psum += pv[t];
+      }
+      uint32_t hw[4], mw[4], lw[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) split3_pair(pv[2 * u], pv[2 * u + 1], hw[u], mw[u], lw[u]);
+      pf[0][kk] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+      pf[1][kk] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
+      pf[2][kk] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+    }
+    l_run = l_run * alpha + psum;
+    // ---- O^T = alpha O^T + V^T . P^T : four 16-row d fragments, two 32-key blocks, six terms
+#pragma unroll
+    for (int fd = 0; fd < 4; ++fd) {
+      o[fd][0] *= alpha; o[fd][1] *= alpha; o[fd][2] *= alpha; o[fd][3] *= alpha;
+      const int d = 16 * fd + r;
+      uint4 vfr[3][2];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) vfr[pl][kk] = *reinterpret_cast<const uint4*>(Vs + (pl * 64 + d) * 128 + (((4 * kk + g) ^ (d & 7)) << 4));
+#define AT_TERM(PV, PP)                                                                                                                   \
+  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) o[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                      \
+      __builtin_bit_cast(bf16x8, vfr[PV][kk]), __builtin_bit_cast(bf16x8, pf[PP][kk]), o[fd], 0, 0, 0);
+      AT_TERM(0, 2) AT_TERM(2, 0) AT_TERM(1, 1) AT_TERM(0, 1) AT_TERM(1, 0) AT_TERM(0, 0)
+#undef AT_TERM
+    }
+  }
+  float l = l_run;
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l;
+  const int qo = q0 + r;
+  if (has_q && qo < S) {
+    const long at = ((long)b * S + qo) * D + h * 64 + g * 4;
+#pragma unroll
+    for (int fd = 0; fd < 4; ++fd) {
+      const float w4[4] = {o[fd][0] * inv, o[fd][1] * inv, o[fd][2] * inv, o[fd][3] * inv};
+      store_split3(out3 + at + fd * 16, plane_out, w4);
+    }
+  }
+}
+
 inline int grid_for(long n, int block) {
   long g = (n + block - 1) / block;
   return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
@@ -809,5 +1014,13 @@ extern "C" int pf_layernorm_split3(const float* x, int x_ld, void* y3, int y_ld,
                                    long rows, int D, void* stream) {
   if (!x || !y3 || !g || !b || D % 8 || D > 2048 || x_ld % 8 || y_ld % 8 || rows <= 0 || plane < (rows - 1) * y_ld + D) return PF_ERR_ARG;
   hipLaunchKernelGGL(layernorm_split3_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST(stream), x, x_ld, (bf16_t*)y3, y_ld, plane, g, b, eps, rows, D);
+  return ok();
+}
+
+extern "C" int pf_vit_attention_split3(const void* qkv3, long plane_in, void* out3, long plane_out, int B, int S, int Hh, void* stream) {
+  if (!qkv3 || !out3 || B <= 0 || S <= 0 || Hh <= 0 || plane_in < (long)B * S * Hh * 192 || plane_out < (long)B * S * Hh * 64) return PF_ERR_ARG;
+  const float qscale = 0.125f * 1.4426950408889634f;        // head_dim^-1/2 (attention.py:55) times log2(e): base-2 softmax
+  hipLaunchKernelGGL(vit_attention_split3_kernel, dim3((S + 63) / 64, B * Hh), dim3(256), 0, ST(stream), (const bf16_t*)qkv3, plane_in, (bf16_t*)out3,
+                     plane_out, B, S, Hh, qscale);
   return ok();
 }

@@ -31,6 +31,12 @@ def linear_split3_enabled():
     return os.environ.get("PF_LINEAR_SPLIT3", "1") != "0"
 
 
+def attention_split3_enabled():
+    """float32 mode with split-precision linears: also run the ViT attention in split precision (pf_vit_attention_split3)?  PF_ATTN_SPLIT3=0 / 1"""
+    import os
+    return os.environ.get("PF_ATTN_SPLIT3", "1") != "0"
+
+
 def bins_tail_enabled():
     """float32 mode: the fused metric-bins tail kernel (pf_bins_tail)?  PF_BINS_TAIL=0 keeps the four separate launches"""
     import os
@@ -256,6 +262,8 @@ class BranchNet:
         mid = ops.empty((B * S, 4 * D), dt, dev)
         if self.split3:                                            # operands of the split GEMMs travel as three bf16 planes
             hbuf, att, mid = (ops.empty((3, B * S, n), torch.bfloat16, dev) for n in (D, D, 4 * D))
+            if attention_split3_enabled():                         # ... and so do q / k / v: attention in split precision (csrc/vit.hip)
+                qkv = ops.empty((3, B * S, 3 * D), torch.bfloat16, dev)
         for i, blk in enumerate(self.blocks):
             if self.split3:
                 ops.layernorm_split3(x, hbuf, blk["n1"][0], blk["n1"][1], 1e-6)

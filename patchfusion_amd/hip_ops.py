@@ -361,6 +361,13 @@ class HipOps:
     def vit_attention(qkv, out, B, S, heads):
         """qkv [B*S, 3*D] -> out [B*S, D]; head_dim must be 64.  float32 qkv with a bfloat16 out [3, B*S, D]: the output is written as
         the three split planes of the projection GEMM (ops.conv_split3)."""
+        if qkv.dim() == 3:
+            # the QKV GEMM's output as three bf16 planes [3, B*S, 3*D]: attention entirely in split precision (csrc/vit.hip)
+            D = qkv.shape[2] // 3
+            assert qkv.dtype == out.dtype == torch.bfloat16 and tuple(qkv.shape) == (3, B * S, 3 * D) and tuple(out.shape) == (3, B * S, D)
+            assert D == heads * 64 and qkv.is_contiguous() and out.is_contiguous()
+            check(_L.pf_vit_attention_split3(_p(qkv), qkv.stride(0), _p(out), out.stride(0), B, S, heads, _stream()), "pf_vit_attention_split3")
+            return
         D = qkv.shape[1] // 3
         assert D == heads * 64 and qkv.is_contiguous() and out.is_contiguous()
         import os

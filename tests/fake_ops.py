@@ -192,6 +192,8 @@ class FakeOps:
 
     @staticmethod
     def vit_attention(qkv, out, B, S, heads):
+        if qkv.dim() == 3:                                   # three bf16 planes of the QKV output: summed back to float32 (exact)
+            qkv = qkv.float().sum(0)
         D = qkv.shape[1] // 3
         q, k, v = qkv.float().view(B, S, 3, heads, D // heads).permute(2, 0, 3, 1, 4)
         a = ((q * (D // heads) ** -0.5) @ k.transpose(-2, -1)).softmax(dim=-1)

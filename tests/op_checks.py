@@ -397,6 +397,32 @@ def vit_attention_split(dt):
             os.environ["PF_ATTN_QKV"] = old
 
 
+def vit_attention_split3(dt):
+    """attention entirely in split precision (pf_vit_attention_split3: q / k / v and the output as three bf16 planes) against float64 on the
+    SAME float32 qkv, next to the f32-MFMA attention kernel's own error: ragged S (last key tile of 13 keys, query blocks without queries),
+    a short sequence, large logits"""
+    o = hip()
+    g = torch.Generator().manual_seed(77)
+    worst, info = 0.0, []
+    for (B, S, heads, scale) in ((2, 1037, 16, 1.0), (1, 70, 2, 3.0), (3, 64, 4, 1.0), (1, 129, 1, 6.0)):
+        D = heads * 64
+        qkv = (torch.randn(B * S, 3 * D, generator=g) * scale).to(DEV)
+        q, k, v = qkv.double().view(B, S, 3, heads, 64).permute(2, 0, 3, 1, 4)
+        ref = (((q * 0.125) @ k.transpose(-2, -1)).softmax(-1) @ v).transpose(1, 2).reshape(B * S, D)
+        den = max(1.0, float(ref.abs().max()))
+        q3 = torch.empty(3, B * S, 3 * D, dtype=torch.bfloat16, device=DEV)
+        o.split3(qkv, q3)
+        o3 = torch.full((3, B * S, D), 7.0, dtype=torch.bfloat16, device=DEV)
+        o.vit_attention(q3, o3, B, S, heads)
+        e3 = float((o3.double().sum(0) - ref).abs().max()) / den
+        of = torch.empty(B * S, D, device=DEV)
+        o.vit_attention(qkv, of, B, S, heads)
+        ef = float((of.double() - ref).abs().max()) / den
+        worst = max(worst, e3)
+        info.append(f"B{B} S{S} h{heads} x{scale}: split {e3:.2e} vs f32 kernel {ef:.2e}")
+    return worst, 3e-6, "; ".join(info)
+
+
 def gemm_split3(dt):
     """split-precision linear layer (csrc/gemm_split3.hip) against float64 on the SAME float32 operands: the three-plane split must be
     exact (h + m + l == x bit for bit), and the GEMM's error must be float32-grade (the dropped terms are O(2^-24) of |x||w|), at a
@@ -731,8 +757,8 @@ CHECKS = {
     "conv_split_n272_res_views": conv_split_n272_res_views, "conv_split_gemm_n544_inplace": conv_split_gemm_n544_inplace,
     "conv_gemm_vitl_linear_shape": conv_gemm_vitl_linear_shape, "conv_bf16_pp": conv_bf16_pp, "conv_dominant_launch": conv_dominant_launch,
     "conv_transpose": conv_transpose, "patch_embed_tokens": patch_embed_tokens, "layernorm": layernorm,
-    "vit_attention": vit_attention, "vit_attention_split": vit_attention_split, "gemm_split3": gemm_split3, "swin_ops": swin_ops, "resize_ops": resize_ops, "roi_ops": roi_ops,
+    "vit_attention": vit_attention, "vit_attention_split": vit_attention_split, "gemm_split3": gemm_split3, "vit_attention_split3": vit_attention_split3, "swin_ops": swin_ops, "resize_ops": resize_ops, "roi_ops": roi_ops,
     "conv_winograd": conv_winograd, "conv_winograd_fused": conv_winograd_fused, "misc_ops": misc_ops, "bins_ops": bins_ops, "bins_tail": bins_tail, "stitch_ops": stitch_ops,
 }
-F32_ONLY = {"bins_ops", "bins_tail", "stitch_ops", "conv_winograd", "conv_winograd_fused", "vit_attention_split", "gemm_split3"}
+F32_ONLY = {"bins_ops", "bins_tail", "stitch_ops", "conv_winograd", "conv_winograd_fused", "vit_attention_split", "gemm_split3", "vit_attention_split3"}
 DTYPES = {"fp32": torch.float32, "bf16": torch.bfloat16}

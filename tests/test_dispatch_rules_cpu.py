@@ -1,0 +1,55 @@
+"""CPU tests of the host-side dispatch rules of round 3 (no kernel is launched): which float32 3x3 layers get which Winograd filters at packing
+time, and which form hip_ops picks per call (fused kernel / three steps with the split or f32 GEMM / direct kernel)."""
+import importlib
+import os
+
+import pytest
+import torch
+
+from patchfusion_amd import packing as pk
+
+
+def _pack(cout, cin, k=3, **kw):
+    return pk.pack_conv(torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5, torch.zeros(cout), dtype=torch.float32, **kw)
+
+
+def test_packing_chooses_winograd_filters_by_layer_shape(monkeypatch):
+    monkeypatch.delenv("PF_WINO_SPLIT3", raising=False)
+    monkeypatch.delenv("PF_WINO_FUSED_SMALL", raising=False)
+    big = _pack(544, 544)                  # three-step eligible: all three filter sets
+    assert big.wino_m == 4 and big.wino_u is not None and big.wino_up is not None and big.wino_u3 is not None
+    assert tuple(big.wino_u3.shape) == (3,) + tuple(big.wino_u.shape) and big.wino_u3.dtype == torch.bfloat16
+    assert bool((big.wino_u3.double().sum(0) == big.wino_u.double()).all())          # the planes are an exact split of G g G^T
+    small = _pack(32, 64)                  # below the three-step channel threshold: fused filters only
+    assert small.wino_m == 4 and small.wino_u is None and small.wino_u3 is None and small.wino_up is not None
+    assert _pack(32, 8).wino_m == 0 and _pack(32, 8).wino_up is None                  # Cin < 32: direct kernel
+    assert _pack(64, 64, k=1).wino_m == 0                                             # not a 3x3 layer
+    assert pk.pack_conv(torch.randn(64, 64, 3, 3), torch.zeros(64), dtype=torch.bfloat16).wino_m == 0
+    assert pk.pack_conv(torch.randn(64, 64, 3, 3), torch.zeros(64), dtype=torch.float32, scale=torch.ones(64)).wino_m == 0   # LayerScale epilogue
+    monkeypatch.setenv("PF_WINO_FUSED_SMALL", "0")
+    assert _pack(32, 64).wino_m == 0
+    monkeypatch.setenv("PF_WINO_SPLIT3", "0")
+    assert _pack(544, 544).wino_u3 is None
+    # applies(): the call-time half
+    assert pk.winograd_applies(small, 10 ** 6, 1, 1, "relu") and not pk.winograd_applies(small, 10 ** 6, 2, 1, None)
+    assert not pk.winograd_applies(small, 10 ** 6, 1, 1, "gelu") and not pk.winograd_applies(_pack(32, 8), 10 ** 6, 1, 1, None)
+
+
+def test_fused_versus_three_step_rule(monkeypatch):
+    try:
+        hip_ops = importlib.import_module("patchfusion_amd.hip_ops")
+    except Exception as e:                 # the product path needs libpf_hip.so even to import (no CPU fallback)
+        pytest.skip(f"libpf_hip.so not built: {e}")
+    for v in ("PF_WINO_FUSED", "PF_WINO_SPLIT3", "PF_WINO_FUSED_SMALL"):
+        monkeypatch.delenv(v, raising=False)
+    p544, p768, p768_256, p64_32 = _pack(544, 544), _pack(768, 768), _pack(256, 768), _pack(32, 64)
+    fw = hip_ops._fused_wanted
+    assert not fw(8, 392, 518, p544) and not fw(8, 224, 296, p768)          # >= 512 output channels: three steps with the split GEMM
+    assert fw(8, 224, 296, p768_256) and fw(8, 392, 518, p64_32)            # fewer: fused kernel
+    assert not fw(1, 28, 37, p768_256) and not fw(1, 56, 74, p64_32)        # too few blocks: three-step / direct
+    monkeypatch.setenv("PF_WINO_SPLIT3", "0")                               # f32 GEMM: the old rule (only 768+ -> 768+ stays three-step)
+    assert fw(8, 392, 518, p544) and not fw(8, 224, 296, p768)
+    monkeypatch.setenv("PF_WINO_FUSED", "0")
+    assert not fw(8, 392, 518, p544) and not fw(8, 392, 518, p64_32)
+    monkeypatch.setenv("PF_WINO_FUSED", "2")
+    assert fw(1, 28, 37, p768)

@@ -8,8 +8,11 @@
 A "step" is one pass of the hot path (coarse branch + G2L + per-tile fine branch + guided fusion + stitch)
 over one synthetic 2160x3840 image that is already resident in HBM.
 
-HEADLINE PRECISION = the reference's: float32 end to end (`dtype: "f32"`, exact mode: f32 storage, f32 MFMA
-v_mfma_f32_16x16x4_f32 = an fma chain, parity bar 2e-4 in depth units against the reference's own outputs).
+HEADLINE PRECISION = the reference's: float32 end to end (`dtype: "f32"`, exact mode: f32 storage and float32-grade arithmetic --
+the f32 MFMA v_mfma_f32_16x16x4_f32, and for the large GEMMs (ViT block linears, attention, the transform-domain GEMM of the widest
+Winograd layers) split-precision products on the bf16 MFMA with f32 accumulation whose error against float64 is measured <= the f32
+MFMA kernels'; `config.precision` says so and the object `f32_mfma_only` carries the same pass with every GEMM on the f32 MFMA; parity
+bar 1e-4 in depth units at this configuration, 2e-4 against the reference's own outputs).
 The fast mode (bf16 storage / bf16 MFMA, f32 accumulation and f32 metric-bins head) is timed on the same image with
 the same K/W and reported in the secondary object `"bf16"` TOGETHER WITH ITS MEASURED ERROR against the f32 map of
 the same run (max / p99 / mean |delta| in depth units) -- it is never the headline `value`.
@@ -20,8 +23,10 @@ the ranks (explicit opt-in shard_patches=True; coarse branch + G2L replicated, n
 depths are all-gathered over RCCL before every rank stitches.  value = tiles of the image / max-over-ranks wall time.
 
 Rank 0 prints ONE JSON line (contract in the task statement) including
-  roofline     : the dominant kernel of the headline mode (3x3 conv 544->544 @ 8x392x518, the largest single op of
-                 the fusion U-Net) timed live with HIP events on its launch stream, vs the dense MFMA peak of the dtype
+  roofline     : the dominant launch of the headline mode (of the 3x3 conv 544->544 @ 8x392x518, the largest single layer of the
+                 fusion U-Net: in the default dispatch the batched split-precision GEMM over its 36 Winograd transform points) timed
+                 live with HIP events on its launch stream: USEFUL float32 FLOPs vs the f32 MFMA peak (+ executed bf16 FLOPs vs the bf16 peak)
+  f32_mfma_only: {value, ms_per_step, ...} the same pass with PF_LINEAR_SPLIT3=0 PF_WINO_SPLIT3=0 (N=1 only)
   bf16         : {value, ms_per_step, err{...}, roofline{...}}  (N=1 only)
   cpu_baseline : kind "reference" = the reference's own PatchFusion (oracle/ref_shim.py) when /root/reference exists
                  on the box, else kind "port" = the oracle (oracle/pf_oracle.py); bounded sample, N=1 rank 0 only
@@ -252,11 +257,12 @@ def roofline(dtype, dev, gemm_only=False):
 
     bf16: the 3x3 halo kernel on the fusion U-Net's 544->544 conv @ [8,392,518]; algorithmic FLOPs = 2 * 8*392*518 * 9*544 * 544 per
     launch.
-    fp32: the large 3x3 layers run as Winograd F(m x m, 3x3) (csrc/winograd.hip); the dominant launch is the f32 implicit-GEMM kernel
-    on the (m+2)^2 transform-point planes of that same layer, one batched launch: FLOPs = (m+2)^2 * 2 * T * 544 * 544 with
-    T = 8 * ceil(392/m) * ceil(518/m) tiles -- the GEMM's OWN multiply-adds, priced against the f32 MFMA peak.  `layer` adds the
-    whole three-step layer: its time and the direct-convolution FLOPs it replaces per second (which may exceed the MFMA peak:
-    Winograd multiplies (m+2)^2 / (9 m^2) as often).  PF_WINOGRAD=0: the direct f32 kernel on the 3x3 layer, as in bf16.
+    fp32: the layer runs as Winograd F(4x4, 3x3); whichever form the engine's dispatch picks for it (hip_ops._fused_wanted) is timed:
+    the batched transform-domain GEMM in split precision (default), the fused kernel (PF_WINO_SPLIT3=0), or the batched f32 GEMM
+    (PF_WINO_FUSED=0 too): FLOPs = 36 * 2 * T * 544 * 544 with T = 8 * ceil(392/4) * ceil(518/4) tiles -- the layer's OWN useful
+    multiply-adds in the transform domain, priced against the f32 MFMA peak.  `layer` adds the whole layer: its time and the
+    direct-convolution FLOPs it replaces per second (which may exceed the MFMA peak: Winograd multiplies 36 / 144 as often).
+    PF_WINOGRAD=0: the direct f32 kernel on the 3x3 layer, as in bf16.
     `traffic` (HBM bytes per launch from the rocprofv3 PMC passes, which cannot run inside bench.py) is reported only when
     profiles/r3_pmc_dominant_<dtype>.json was measured on EXACTLY this kernel source (sha of igemm.hip + wino_fused.hip + pf_common.h); otherwise null.
     NOTE on its meaning: FETCH_SIZE / WRITE_SIZE count the L2's fabric-side requests; reads served by the 256 MiB Infinity Cache are included, so

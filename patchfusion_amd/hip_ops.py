@@ -315,8 +315,10 @@ class HipOps:
         p.KH = p.KW = p.stride = 1
         p.act, p.shuffle, p.dtype = ACT[act], 1, 1
         for t in (x3, y, pw.w, res, res2):
-            _p(t)
-            assert t is None or t is x3 or t is y or t is pw.w or t.dtype == torch.float32
+            _p(t)                                             # (device / layout checks of every tensor handed to the library)
+        for t in (res, res2):
+            assert t is None or (t.dtype == torch.float32 and t.shape[-1] >= pw.cout and t.shape[-2] == M), "residuals are float32 [M, >= N]"
+        assert (y.shape[-1] >= pw.cout and y.shape[-2] == M) and x3.shape[2] >= pw.cin
         if _timed is not None:
             ms = C.c_float(0)
             check(_L.pf_gemm_split3_timed(C.byref(p), int(_timed), C.byref(ms), _stream()), "pf_gemm_split3_timed")

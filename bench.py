@@ -107,12 +107,15 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    mem, rank_s = {}, {}
+
     def run_mode(dtype):
         """W untimed + K timed steps of the whole hot path in `dtype`; -> (seconds for K steps, last depth map)."""
         model = PatchFusion(cfg, compute_dtype=dtype, shard_patches=world > 1).eval()
         model.load_state_dict(sd, strict=True)
         model = model.to(dev)
         lr = model.resizer(img)
+        torch.cuda.reset_peak_memory_stats(dev)
 
         def step():
             d, _ = model(mode="infer", image_lr=lr, image_hr=img, cai_mode="m1", process_num=args.process_num)
@@ -131,9 +134,13 @@ def main():
         dt = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            dt = float(t.item())
+            every = [torch.zeros_like(t) for _ in range(world)]
+            torch.distributed.all_gather(every, t)           # per-rank wall times: a straggler GPU is visible in the line
+            rank_s[dtype] = [round(float(v.item()), 4) for v in every]
+            dt = max(rank_s[dtype])
         log(f"{dtype}: timed {args.steps} steps: {dt:.3f}s")
+        mem[dtype] = {"max_allocated_GB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
+                      "max_reserved_GB": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 2)}
         d = d.float().clone()
         del model
         torch.cuda.empty_cache()
@@ -160,6 +167,10 @@ def main():
                    "parallelism": f"patch-sharded x{N}, coarse+G2L replicated, RCCL all_gather of tile depths" if N > 1 else "single GPU"},
     }
 
+    out["memory"] = dict(mem[args.dtype], note="torch allocator peak on rank 0 over warm-up + timed steps: weights (two f32 checkpoints + packed "
+                         "copies), activations of process_num tiles on two streams, the three-step Winograd V/M arenas (one pair per stream)")
+    if world > 1:
+        out["rank_seconds"] = rank_s[args.dtype]
     if rank == 0 and not args.no_roofline:
         out["roofline"] = roofline(args.dtype, dev)
         log(f"roofline: {out['roofline']}")
@@ -201,8 +212,8 @@ def main():
 
 
 PRECISION_F32 = {
-    True: "float32 storage; convolutions and attention on the f32 MFMA, except the two GEMM families that run in split precision: the ViT block "
-          "linears and the transform-domain GEMM of the Winograd layers with >= 512 output channels (each f32 operand = three bf16 planes, six "
+    True: "float32 storage; convolutions on the f32 MFMA, except the GEMM families that run in split precision: the ViT block linears, the ViT "
+          "attention (QK^T and PV) and the transform-domain GEMM of the three-step Winograd layers (each f32 operand = three bf16 planes, six "
           "partial products on the bf16 MFMA, f32 accumulation: error vs float64 <= the f32 MFMA kernel's, tests/op_checks.py gemm_split3; "
           "PF_LINEAR_SPLIT3=0 PF_WINO_SPLIT3=0 -> f32_mfma_only)",
     False: "float32 storage + f32 MFMA everywhere (exact mode = the reference's precision)"}
@@ -303,18 +314,23 @@ def roofline(dtype, dev, gemm_only=False):
             y = torch.empty(B, H, W, C, device=dev)
             ms_layer = ops.conv(x, pw, y, pad=1, act="relu", _timed=5)
         try:
-            with open(os.path.join(ROOT, "profiles", "r3_pmc_dominant_fp32.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r4_pmc_dominant_fp32.json")) as f:
                 j = json.load(f)
             traffic = j["derived"]["traffic_bytes"] if j.get("kernel_source_sha") == kernel_source_sha() else None
         except Exception:
             traffic = None
+        # the pipe this launch executes on is the bf16 MFMA, six instructions per useful float32 product: its ceiling for float32-grade work
+        # is 2500 / 6 = 416.7 TF/s, and THAT is `peak` (round-3 review: pricing it against the 157.3 TF/s f32 MFMA peak, a pipe the kernel never
+        # touches, printed 0.96 for a launch whose matrix pipe was 48 % busy)
+        peak = PEAK_TFLOPS["bf16"] / 6.0
         return {"bound": "mfma",
-                "kernel": f"gemm_split3_kernel (6 x v_mfma_f32_16x16x32_bf16 per float32 product, f32 accumulation) as the batched transform-domain GEMM of the "
+                "kernel": f"gemm_split3_persist_kernel (6 x v_mfma_f32_16x16x32_bf16 per float32 product, f32 accumulation) as the batched transform-domain GEMM of the "
                           f"largest layer: 36 planes x [{T} x {C}].[{C} x {C}] = 3x3 {C}->{C} @ {B}x{H}x{W} (GuidedFusion up-conv) under Winograd F(4x4,3x3)",
-                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "traffic": traffic, "winograd_m": 4,
-                "note": "achieved / peak = USEFUL float32 FLOPs of the launch over the f32 MFMA peak (157.3 TF/s); the launch executes 6x as many bf16 "
-                        "FLOPs: see executed_bf16",
+                "note": "achieved = USEFUL float32 FLOPs of the launch per second; peak = the dense bf16 MFMA peak / 6 (six bf16 MFMAs per float32-grade "
+                        "product), so frac = executed bf16 FLOPs (padding columns not counted) over the 2.5 PF/s bf16 peak",
+                "vs_f32_mfma_peak": round(ach / PEAK_TFLOPS["fp32"], 4),
                 "executed_bf16": {"tflops": round(6 * ach, 1), "peak": PEAK_TFLOPS["bf16"], "frac": round(6 * ach / PEAK_TFLOPS["bf16"], 4)},
                 "layer": None if ms_layer is None else {
                     "what": f"whole layer = input transform (split planes) + batched GEMM + output transform/epilogue, 3x3 {C}->{C} @ {B}x{H}x{W}",

@@ -304,7 +304,277 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split3_kernel(const pf_conv
   }
 }
 
+// ---- PERSISTENT ping-pong form (round 4) -----------------------------------------------------------------------------------------------------
+// One resident block per CU walks its share of the 128 x 128 output tiles; the K chunks of consecutive tiles form ONE stream through the
+// three-slot ring, so the first three chunks of tile t+1 are in flight under the last MFMAs of tile t, and the epilogue of tile t (stores only;
+// the accumulators are re-zeroed) sits at the head of the load phase M of tile t+1's first chunk, i.e. beside the partner group's MFMAs.
+// The one-tile-per-block kernel above pays launch + ring fill + drain + store tail per tile with nothing else resident on the CU (144 KiB of
+// LDS): ~10 us of a 22-25 us tile at K = 544 (profiles/r3_split3_gemm_decomp.log: 75 of 369 us with no MFMA, DMA or fragment read at all).
+// Tile order: block b runs on XCD b % 8 (observed; locality only).  XCD x owns the contiguous tile range [total x / 8, total (x+1) / 8); in
+// iteration i its local block j takes tile lo + i nb + j, so the ~32 tiles an XCD works on at once are consecutive in the order
+//   plane z  >  groups of gm token tiles  >  channel tile  >  token tile within the group           (gm = 32 / nt for nt <= 6, else 8)
+// = a gm x (32 / gm) patch whose X and W panels are fetched into that XCD's L2 once and shared.
+// Loader: every DMA piece (16 rows of one plane) has a wave-uniform 64-bit base in SGPRs (tile origin + plane, advanced by 64 B per chunk with
+// scalar adds) and a per-lane 32-bit offset (row x ld + swizzled slot) that changes only with the tile's row clamp: rows beyond M / w_rows
+// are clamped to the last valid row instead of reading a zero page -- their products land in accumulator rows / columns that are never stored.
+// BARE: plain float32 store (the batched transform-domain GEMM of a Winograd layer); otherwise the full pf_conv epilogue.
+__device__ __forceinline__ void glds16s(unsigned voff, unsigned long long sbase, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
+
+template <bool BARE>
+__global__ __launch_bounds__(512) void gemm_split3_persist_kernel(const pf_conv_params p, int mt, int nt, int gm, int total) {
+  constexpr int BM = 128, BN = 128, WM = 4, WN = 2, NP = 3, NS = 3;
+  constexpr int NW = WM * WN;
+  constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 16, FN = WTN / 16;
+  constexpr int ROWS = NP * (BM + BN), PIECES = ROWS / 16, PPW = PIECES / NW;
+  constexpr int STAGE = ROWS * 64;
+  static_assert(PPW * 16 * WM == NP * BM && WM * 2 == NW && BM == BN, "waves 0..3 stage the X planes, waves 4..7 the W planes");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int M = p.B * p.OH * p.OW;
+  const int nk = p.Cin / 32;
+
+  // ---- this block's tiles
+  const int G = (int)gridDim.x, xcd = (int)blockIdx.x & 7, nb = (G - xcd + 7) >> 3;
+  const int lo = (int)((long)total * xcd / 8), hi = (int)((long)total * (xcd + 1) / 8);
+  const int l_first = lo + ((int)blockIdx.x >> 3);
+  if (l_first >= hi) return;
+  const int my_tiles = (hi - l_first + nb - 1) / nb;
+  const int chunks = my_tiles * nk;
+  const int per_plane = mt * nt, per_group = gm * nt;
+  auto decode = [&](int l, int& z, int& m0, int& n0) __attribute__((always_inline)) {
+    z = l / per_plane;
+    const int r = l - z * per_plane;
+    const int group = r / per_group, in_g = r - group * per_group, first = group * gm;
+    const int gsz = min(mt - first, gm);
+    const int tn = in_g / gsz;
+    m0 = (first + in_g - tn * gsz) * BM;
+    n0 = tn * BN;
+  };
+
+  // ---- loader: wave w moves pieces w*PPW .. +PPW-1 of a stage [X h | X m | X l | W h | W m | W l]; lane L -> row 16 q + (L >> 2),
+  // physical slot L & 3 = logical slot ^ ((row >> 1) & 3)
+  const bool is_x = wave < WM;
+  const int ld_b = (is_x ? p.x_ld : p.Kpad) * 2;                              // operand row pitch in bytes
+  const int lim = is_x ? M : p.w_rows;
+  const unsigned long long op_base = is_x ? (unsigned long long)p.x : (unsigned long long)p.w;
+  const unsigned long long pl_b = (unsigned long long)(is_x ? p.x_bstride : p.w_bstride) * 2;   // h / m / l plane pitch in bytes
+  const unsigned long long z_b = (unsigned long long)lim * ld_b;              // transform-point pitch (batched) in bytes
+  unsigned long long sbase[PPW];
+  unsigned voff[PPW];
+  auto setup_loader = [&](int l) __attribute__((always_inline)) {
+    int z, m0, n0;
+    decode(l, z, m0, n0);
+    const int origin = is_x ? m0 : n0;
+    const unsigned long long tb = op_base + (unsigned long long)z * z_b + (unsigned long long)origin * ld_b;
+    const int last = lim - 1 - origin;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int row = ((wave & (WM - 1)) * PPW + i) * 16 + (lane >> 2);          // row within this operand's three planes
+      const int j = (lane & 3) ^ ((row >> 1) & 3);                               // (BM is a multiple of 4: same swizzle as the stage row)
+      const int pl = ((wave & (WM - 1)) * PPW + i) / (BM / 16), r = row - pl * BM;
+      sbase[i] = tb + pl * pl_b;
+      voff[i] = (unsigned)(min(r, last) * ld_b + j * 16);
+    }
+  };
+  const unsigned smem_base = lds_addr(smem);
+  int l_load = l_first, l_kc = 0, s_issue = 0;
+  setup_loader(l_load);
+  auto issue = [&]() __attribute__((always_inline)) {
+    // (readfirstlane: the ring position is wave-uniform by construction, but hipcc's divergence analysis loses that through the tile walk)
+    const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + s_issue * STAGE + wave * (PPW * 1024));
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      glds16s(voff[i], sbase[i], dst + i * 1024);
+      sbase[i] += 64;
+    }
+    s_issue = s_issue == NS - 1 ? 0 : s_issue + 1;
+    if (++l_kc == nk) {                                  // the stream moves on to this block's next tile
+      l_kc = 0;
+      l_load += nb;
+      if (l_load < hi) setup_loader(l_load);
+    }
+  };
+
+  f32x4 acc[FN][FM];
+#pragma unroll
+  for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) acc[fn][fm] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fg = lane >> 4;
+  const int slot = (fg ^ ((fr >> 1) & 3)) << 4;
+  const int x_off = (wm * WTM + fr) * 64 + slot;
+  const int w_off = NP * BM * 64 + (wn * WTN + fr) * 64 + slot;
+  struct Frags { uint4 w[NP][FN], x[NP][FM]; };
+  int s_read = 0;
+  auto read_frags = [&](Frags& f) __attribute__((always_inline)) {
+    const char* S = smem + s_read * STAGE;
+    s_read = s_read == NS - 1 ? 0 : s_read + 1;
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn) f.w[pl][fn] = *reinterpret_cast<const uint4*>(S + w_off + pl * (BN * 64) + fn * 1024);
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm) f.x[pl][fm] = *reinterpret_cast<const uint4*>(S + x_off + pl * (BM * 64) + fm * 1024);
+    }
+  };
+  auto multiply = [&](const Frags& f) __attribute__((always_inline)) {
+#define S3_TERM(PW, PX)                                                                                                      \
+  _Pragma("unroll") for (int fn = 0; fn < FN; ++fn) _Pragma("unroll") for (int fm = 0; fm < FM; ++fm)                       \
+      acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.w[PW][fn]), __builtin_bit_cast(bf16x8, f.x[PX][fm]), \
+                                                            acc[fn][fm], 0, 0, 0);
+    S3_TERM(0, 2) S3_TERM(2, 0) S3_TERM(1, 1) S3_TERM(0, 1) S3_TERM(1, 0) S3_TERM(0, 0)
+#undef S3_TERM
+  };
+
+  // ---- epilogue of the tile whose last chunk was just multiplied: coordinates decoded in that chunk's load phase, stores one phase later
+  int l_comp = l_first, c_kc = 0;
+  int e_z = 0, e_m0 = 0, e_n0 = 0;
+  bool epi_pending = false;
+  // (the per-channel vectors are fetched here, channel fragment by channel fragment -- L2-resident, and the whole epilogue runs beside the partner
+  // group's MFMAs; holding them over the tile's last chunk as the one-tile kernel does costs 32 registers and spills)
+  auto epilogue = [&]() __attribute__((always_inline)) {
+    const long y_base = (long)e_z * M * p.y_ld;
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) {
+      const int n = e_n0 + wn * WTN + fn * 16 + fg * 4;
+      float4 bias_r = make_float4(0.f, 0.f, 0.f, 0.f), scale_r = make_float4(1.f, 1.f, 1.f, 1.f);
+      if constexpr (!BARE) {
+        __builtin_amdgcn_sched_barrier(0);                 // one channel fragment at a time: hoisting every residual load of the tile costs
+                                                           // registers the live fragment set does not leave
+        if (n < p.Cout) {
+          if (p.bias) bias_r = *reinterpret_cast<const float4*>(p.bias + n);
+          if (p.scale) scale_r = *reinterpret_cast<const float4*>(p.scale + n);
+        }
+      }
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm) {
+        const int m = e_m0 + wm * WTM + fm * 16 + fr;
+        if (m < M && n < p.Cout) {
+          if constexpr (BARE) {
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + y_base + (long)m * p.y_ld + n) = acc[fn][fm];
+          } else {
+            float v[4] = {acc[fn][fm][0] + bias_r.x, acc[fn][fm][1] + bias_r.y, acc[fn][fm][2] + bias_r.z, acc[fn][fm][3] + bias_r.w};
+            if (p.act == PF_ACT_RELU) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            } else if (p.act == PF_ACT_GELU) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            } else if (p.act == PF_ACT_SOFTPLUS) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = softplus20(v[r]);
+            }
+            v[0] *= scale_r.x; v[1] *= scale_r.y; v[2] *= scale_r.z; v[3] *= scale_r.w;
+            if (p.res) {
+              const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) + (long)m * p.res_ld + n);
+              v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+            }
+            if (p.res2) {
+              const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res2) + (long)m * p.res2_ld + n);
+              v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+            }
+            if (p.out_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + y_base + (long)m * p.y_ld + n) = make_float4(v[0], v[1], v[2], v[3]);
+            else store_split3(reinterpret_cast<bf16_t*>(p.y) + (long)m * p.y_ld + n, p.y_bstride, v);
+          }
+        }
+        acc[fn][fm] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    epi_pending = false;
+  };
+
+  // ---- the chunk stream (schedule and hazards: see the ping-pong branch of gemm_split3_kernel; tests/test_split3_schedule_model_cpu.py
+  // replays this control flow, tile switches included)
+#pragma nounroll
+  for (int i = 0; i < NS; ++i)
+    if (i < chunks) issue();
+  if (chunks > 2) vm_wait<PPW>();                       // chunks 0 and 1 landed
+  else vm_wait<0>();
+  lds_barrier();
+  Frags fa, fb;
+  read_frags(fa);
+  lds_barrier();
+  const bool grp_b = wave >= NW / 2;
+  if (grp_b) plain_barrier();                           // one phase behind
+  // phase M(g): [stores of the tile that ended with chunk g-1], DMA of chunk g+3, fragments of chunk g+1, wait for this wave's pieces of g+2;
+  // phase C(g): the 48 MFMAs of chunk g out of registers
+  auto pp_chunk = [&](const Frags& cf, Frags& nf, int g) __attribute__((always_inline)) {
+    if (epi_pending) epilogue();                        // beside the partner group's MFMAs
+    if (c_kc == nk - 1) {                               // chunk g ends a tile
+      decode(l_comp, e_z, e_m0, e_n0);
+      l_comp += nb;
+    }
+    if (g + 3 < chunks) issue();
+    if (g + 1 < chunks) read_frags(nf);
+    if (g + 3 < chunks) vm_wait<PPW>();
+    else if (g + 2 < chunks) vm_wait<0>();
+    lds_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    multiply(cf);
+    __builtin_amdgcn_s_setprio(0);
+    if (++c_kc == nk) { c_kc = 0; epi_pending = true; }
+    plain_barrier();
+  };
+#pragma nounroll
+  for (int g = 0; g < chunks; g += 2) {
+    pp_chunk(fa, fb, g);
+    if (g + 1 < chunks) pp_chunk(fb, fa, g + 1);
+  }
+  if (!grp_b) plain_barrier();
+  epilogue();
+}
+
 thread_local char g_err[200] = {0};
+
+int cu_count() {
+  static std::atomic<int> cus[64];
+  int dev = 0;
+  hipGetDevice(&dev);
+  int c = cus[dev & 63].load(std::memory_order_relaxed);
+  if (c <= 0) {
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+    cus[dev & 63].store(c, std::memory_order_relaxed);
+  }
+  return c;
+}
+
+// persistent launch: 128 x 128 tiles, one block per CU (grid = a multiple of 8 so that every XCD has blocks)
+int launch_persist(const pf_conv_params& p, hipStream_t st) {
+  constexpr int smem = 3 * 3 * (128 + 128) * 64;
+  static std::atomic<unsigned long long> done{0};
+  int dev = 0;
+  hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split3_persist_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split3_persist_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    done.fetch_or(bit, std::memory_order_release);
+  }
+  const long M = (long)p.B * p.OH * p.OW;
+  const int mt = (int)((M + 127) / 128), nt = (p.Cout + 127) / 128;
+  const long total = (long)mt * nt * (p.batch > 1 ? p.batch : 1);
+  const int gm = nt <= 6 ? 32 / nt : 8;
+  int grid = cu_count();
+  if (const char* s = getenv("PF_S3_GRID")) grid = atoi(s);              // (tests: fewer blocks than CUs = more tiles per block; read per call)
+  if (grid > total) grid = (int)total;
+  grid &= ~7;
+  if (grid < 8 || total > 0x7fffffffL) return PF_ERR_ARG;
+  const bool bare = !p.bias && !p.scale && !p.res && !p.res2 && p.act == PF_ACT_NONE && p.out_f32;
+  if (bare) hipLaunchKernelGGL(gemm_split3_persist_kernel<true>, dim3((unsigned)grid), dim3(512), smem, st, p, mt, nt, gm, (int)total);
+  else hipLaunchKernelGGL(gemm_split3_persist_kernel<false>, dim3((unsigned)grid), dim3(512), smem, st, p, mt, nt, gm, (int)total);
+  return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_LAUNCH;
+}
 
 template <int BM, int BN, int WM, int WN, int NS, bool PP = false, int NP = 3, bool PLAIN = false>
 int launch(const pf_conv_params& p, hipStream_t st) {
@@ -352,6 +622,11 @@ extern "C" int pf_gemm_split3(const pf_conv_params* p, void* stream) {
   const long t128 = ((M + 127) / 128) * ((p->Cout + 127) / 128);
   const bool small = force ? force == 64 : t128 < 256;       // (ping-pong 128 x 128 wins from one full round of tiles on: profiles/r3_split3_pingpong.log)
     if (small) return launch<64, 128, 2, 2, 2>(*p, st);
+  // from two full rounds of tiles on: the persistent tile walk (one block per CU, chunk stream continuous across tiles); PF_S3_PERSIST=0 = A/B
+  const char* ps = getenv("PF_S3_PERSIST");
+  const long planes = p->batch > 1 ? p->batch : 1;
+  if (!(ps && ps[0] == '0') && p->Cin >= 96 && (t128 * planes >= 2L * cu_count() || (ps && ps[0] == '2')) && t128 * planes >= 8)
+    return launch_persist(*p, st);
   const char* pp = getenv("PF_S3_PP");                    // (A/B switch; read per call)
   return (pp && pp[0] == '0') ? launch<128, 128, 4, 2, 3, false>(*p, st) : launch<128, 128, 4, 2, 3, true>(*p, st);
 }

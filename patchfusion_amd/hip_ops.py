@@ -244,22 +244,32 @@ class HipOps:
         return y
 
     @staticmethod
-    def gemm_planes_split3_timed(V3, U3, Mw, T, cin, cout, iters):
-        """time the batched split-precision GEMM launch of a three-step Winograd layer alone (bench.py roofline), exactly as
-        csrc/winograd.hip run_split3 issues it: V3 bf16 [3, 36, T, cin], U3 bf16 [3, 36, rows, Kpad], Mw float32 [36, T, cout]"""
-        assert V3.dtype == U3.dtype == torch.bfloat16 and Mw.dtype == torch.float32 and tuple(V3.shape) == (3, 36, T, cin) and U3.shape[:2] == (3, 36)
+    def gemm_planes_split3(V3, U3, Mw, T, cin, cout, iters=None):
+        """the batched split-precision GEMM launch of a three-step Winograd layer alone, exactly as csrc/winograd.hip run_split3 issues it:
+        V3 bf16 [3, P, T, cin], U3 bf16 [3, P, rows, Kpad], Mw float32 [P, T, cout] (P = 36 transform points there); iters = None runs it
+        once, else returns the average milliseconds of `iters` launches (HIP events on the launch stream; bench.py roofline)"""
+        P = V3.shape[1]
+        assert V3.dtype == U3.dtype == torch.bfloat16 and Mw.dtype == torch.float32 and tuple(V3.shape) == (3, P, T, cin) and U3.shape[:2] == (3, P)
+        assert V3.is_contiguous() and U3.is_contiguous() and Mw.is_contiguous() and Mw.numel() >= P * T * cout
         p = ConvParams()
         p.x, p.x_ld, p.B, p.H, p.W, p.Cin = V3.data_ptr(), cin, 1, 1, T, cin
         p.w, p.w_rows, p.Kpad = U3.data_ptr(), U3.shape[2], U3.shape[3]
         p.y, p.y_ld, p.OH, p.OW, p.Cout = Mw.data_ptr(), cout, 1, T, cout
         p.KH = p.KW = p.stride = 1
-        p.act, p.shuffle, p.dtype, p.out_f32, p.batch = 0, 1, 1, 1, 36
+        p.act, p.shuffle, p.dtype, p.out_f32, p.batch = 0, 1, 1, 1, P
         p.x_bstride, p.w_bstride = V3.stride(0), U3.stride(0)
         for t in (V3, U3, Mw):
             _p(t)
+        if iters is None:
+            check(_L.pf_gemm_split3(C.byref(p), _stream()), "pf_gemm_split3")
+            return Mw
         ms = C.c_float(0)
         check(_L.pf_gemm_split3_timed(C.byref(p), int(iters), C.byref(ms), _stream()), "pf_gemm_split3_timed")
         return ms.value
+
+    @staticmethod
+    def gemm_planes_split3_timed(V3, U3, Mw, T, cin, cout, iters):
+        return HipOps.gemm_planes_split3(V3, U3, Mw, T, cin, cout, iters)
 
     @staticmethod
     def gemm_planes_timed(V, U, Mw, planes, T, cin, cout, iters):

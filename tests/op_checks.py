@@ -466,8 +466,14 @@ def gemm_split3(dt):
         den = max(1.0, float(ref.abs().max()))
         x3 = torch.empty(3, M, K, dtype=torch.bfloat16, device=DEV)
         o.split3(x, x3)
-        for force in ("64", "128"):
-            os.environ["PF_S3_TILE_NOW"] = force
+        for force in ("64", "128", "persist16", "persist64"):
+            # persist<G>: the persistent tile walk (csrc/gemm_split3.hip gemm_split3_persist_kernel) forced on these small shapes with a
+            # G-block grid, so that every block crosses several tile boundaries (ragged last token tile, N = 544 = 4 x 128 + 32)
+            os.environ["PF_S3_TILE_NOW"] = "128" if force.startswith("persist") else force
+            if force.startswith("persist"):
+                os.environ["PF_S3_PERSIST"], os.environ["PF_S3_GRID"] = "2", force[7:]
+            else:
+                os.environ["PF_S3_PERSIST"] = "0"
             y = torch.zeros(M, N, device=DEV)
             o.conv_split3(x3, pw3, y, act=act, res=r1, res2=r2)
             y3 = torch.zeros(3, M, N, dtype=torch.bfloat16, device=DEV)
@@ -475,7 +481,8 @@ def gemm_split3(dt):
             e1 = float((y.double() - ref).abs().max()) / den
             e3 = float((y3.double().sum(0) - ref).abs().max()) / den
             errs += [e1, e3]
-        os.environ.pop("PF_S3_TILE_NOW", None)
+        for k in ("PF_S3_TILE_NOW", "PF_S3_PERSIST", "PF_S3_GRID"):
+            os.environ.pop(k, None)
         yf = torch.zeros(1, 1, M, N, device=DEV)
         o.conv(x.view(1, 1, M, K), pw, yf, act=act, res=r1.view(1, 1, M, N) if res else None, res2=r2.view(1, 1, M, N) if res2 else None)
         ef = float((yf.view(M, N).double() - ref).abs().max()) / den
@@ -498,6 +505,43 @@ def gemm_split3(dt):
     if not (ln_same and at_same):
         return float("inf"), 2e-6, "; ".join(info)
     return max(errs), 2e-6, "; ".join(info)
+
+
+def gemm_split3_persist(dt):
+    """the persistent tile walk of the split-precision GEMM (csrc/gemm_split3.hip, round 4) on the launch it was built for -- the BATCHED
+    transform-domain GEMM of a three-step Winograd layer (planes = transform points, plain float32 store): bit-identical to the one-tile-per-block
+    kernel (same chunk order, same six terms per accumulator) for several grid sizes, odd and even chunk counts, a ragged last token tile and
+    N = 544 (five channel tiles, the last with 32 live columns); and float32-grade against float64."""
+    import os
+    o = hip()
+    g = torch.Generator().manual_seed(77)
+    worst, info = 0.0, []
+    for (P, T, cin, cout, grids) in ((5, 1000, 544, 544, ("8", "40", "256")), (3, 517, 96, 160, ("8", "24")), (36, 300, 128, 256, ("64", "256")),
+                                     (2, 2100, 1024, 128, ("16",))):
+        V = torch.randn(P, T, cin, generator=g)
+        U = torch.randn(P, cout, cin, generator=g) / cin ** 0.5
+        rows = -(-cout // 16) * 16
+        Up = torch.zeros(P, rows, cin)
+        Up[:, :cout] = U
+        V3 = torch.stack(pk.split3(V)).contiguous().to(DEV)
+        U3 = torch.stack(pk.split3(Up)).contiguous().to(DEV)
+        ref = torch.einsum("ptk,pnk->ptn", V.double().to(DEV), U.double().to(DEV))
+        den = max(1.0, float(ref.abs().max()))
+        os.environ["PF_S3_TILE_NOW"], os.environ["PF_S3_PERSIST"] = "128", "0"
+        y0 = torch.full((P, T, cout), float("nan"), device=DEV)
+        o.gemm_planes_split3(V3, U3, y0, T, cin, cout)
+        e0 = float((y0.double() - ref).abs().max()) / den
+        same = True
+        for gr in grids:
+            os.environ["PF_S3_PERSIST"], os.environ["PF_S3_GRID"] = "2", gr
+            y1 = torch.full((P, T, cout), float("nan"), device=DEV)
+            o.gemm_planes_split3(V3, U3, y1, T, cin, cout)
+            same = same and bool((y1 == y0).all())
+        for k in ("PF_S3_TILE_NOW", "PF_S3_PERSIST", "PF_S3_GRID"):
+            os.environ.pop(k, None)
+        info.append(f"P{P} T{T} {cin}->{cout}: err {e0:.2e} persistent==one-tile {same}")
+        worst = max(worst, e0 if same else float("inf"))
+    return worst, 2e-6, "; ".join(info)
 
 
 def swin_ops(dt):
@@ -757,8 +801,8 @@ CHECKS = {
     "conv_split_n272_res_views": conv_split_n272_res_views, "conv_split_gemm_n544_inplace": conv_split_gemm_n544_inplace,
     "conv_gemm_vitl_linear_shape": conv_gemm_vitl_linear_shape, "conv_bf16_pp": conv_bf16_pp, "conv_dominant_launch": conv_dominant_launch,
     "conv_transpose": conv_transpose, "patch_embed_tokens": patch_embed_tokens, "layernorm": layernorm,
-    "vit_attention": vit_attention, "vit_attention_split": vit_attention_split, "gemm_split3": gemm_split3, "vit_attention_split3": vit_attention_split3, "swin_ops": swin_ops, "resize_ops": resize_ops, "roi_ops": roi_ops,
+    "vit_attention": vit_attention, "vit_attention_split": vit_attention_split, "gemm_split3": gemm_split3, "gemm_split3_persist": gemm_split3_persist, "vit_attention_split3": vit_attention_split3, "swin_ops": swin_ops, "resize_ops": resize_ops, "roi_ops": roi_ops,
     "conv_winograd": conv_winograd, "conv_winograd_fused": conv_winograd_fused, "misc_ops": misc_ops, "bins_ops": bins_ops, "bins_tail": bins_tail, "stitch_ops": stitch_ops,
 }
-F32_ONLY = {"bins_ops", "bins_tail", "stitch_ops", "conv_winograd", "conv_winograd_fused", "vit_attention_split", "gemm_split3", "vit_attention_split3"}
+F32_ONLY = {"bins_ops", "bins_tail", "stitch_ops", "conv_winograd", "conv_winograd_fused", "vit_attention_split", "gemm_split3", "gemm_split3_persist", "vit_attention_split3"}
 DTYPES = {"fp32": torch.float32, "bf16": torch.bfloat16}

@@ -70,6 +70,63 @@ def ring2(nk, wave):
         yield ("mfma", kc)
 
 
+def persist_pingpong(nk, tiles, wave, log):
+    """gemm_split3_persist_kernel (round 4): `tiles` tiles of `nk` chunks each form ONE chunk stream; statement by statement the C++ control flow,
+    with the loader's tile cursor (l_load, l_kc), the compute cursor (l_comp, c_kc) and the deferred epilogue.  `log` collects
+    ("load", g, tile, kc) / ("mfma", g, tile) / ("store", tile) records for the cursor checks."""
+    NS = 3
+    chunks = tiles * nk
+    st = {"l_load": 0, "l_kc": 0, "issued": 0}
+
+    def issue():
+        log.append(("load", st["issued"], st["l_load"], st["l_kc"]))
+        ev = ("issue", st["issued"])
+        st["issued"] += 1
+        st["l_kc"] += 1
+        if st["l_kc"] == nk:
+            st["l_kc"] = 0
+            st["l_load"] += 1
+        return ev
+    for i in range(NS):
+        if i < chunks:
+            yield issue()
+    yield ("wait", 1 if chunks > 2 else 0)
+    yield ("barrier", True)
+    yield ("read", 0)
+    yield ("barrier", True)
+    grp_b = wave >= NW // 2
+    if grp_b:
+        yield ("barrier", False)
+    l_comp, c_kc, e_tile, epi_pending = 0, 0, None, False
+    for g in range(chunks):
+        if epi_pending:
+            log.append(("store", e_tile))
+            epi_pending = False
+        if c_kc == nk - 1:
+            e_tile = l_comp
+            l_comp += 1
+        if g + 3 < chunks:
+            yield issue()
+        if g + 1 < chunks:
+            yield ("read", g + 1)
+        if g + 3 < chunks:
+            yield ("wait", 1)
+        elif g + 2 < chunks:
+            yield ("wait", 0)
+        yield ("barrier", True)
+        log.append(("mfma", g, l_comp - 1 if c_kc == nk - 1 else l_comp))
+        yield ("mfma", g)
+        c_kc += 1
+        if c_kc == nk:
+            c_kc = 0
+            epi_pending = True
+        yield ("barrier", False)
+    if not grp_b:
+        yield ("barrier", False)
+    assert epi_pending
+    log.append(("store", e_tile))
+
+
 def simulate(schedule, nk, NS):
     gens = [schedule(nk, w) for w in range(NW)]
     issued = [[] for _ in range(NW)]             # per wave: chunks in issue order (in-order DMA queue)
@@ -142,3 +199,59 @@ def test_the_model_catches_a_missing_wait():
             yield ev
     with pytest.raises(AssertionError, match="R1"):
         simulate(broken, 8, 3)
+
+
+@pytest.mark.parametrize("nk,tiles", [(1, 1), (1, 5), (2, 3), (3, 1), (3, 4), (4, 3), (17, 1), (17, 2), (17, 9), (32, 7), (5, 8)])
+def test_persistent_tile_walk_is_hazard_free_and_keeps_its_cursors(nk, tiles):
+    """the persistent kernel's chunk stream obeys the ring rules R1 / R2 across tile boundaries, the loader's cursor names tile g // nk, chunk
+    g % nk for stream position g, every chunk is multiplied into the accumulators of its own tile, and tile t is stored exactly once: after its
+    last chunk's MFMAs and before the first MFMAs of tile t + 1"""
+    logs = [[] for _ in range(NW)]
+    simulate(lambda n, w: persist_pingpong(nk, tiles, w, logs[w]), nk * tiles, 3)
+    for w in range(NW):
+        loads = [r for r in logs[w] if r[0] == "load"]
+        assert [(r[1], r[2], r[3]) for r in loads] == [(g, g // nk, g % nk) for g in range(nk * tiles)]
+        seq = [r for r in logs[w] if r[0] != "load"]
+        stored, cur = [], 0
+        for r in seq:
+            if r[0] == "mfma":
+                assert r[2] == r[1] // nk, r
+                assert stored == list(range(r[2])), f"wave {w}: chunk {r[1]} of tile {r[2]} multiplied while tiles {stored} are stored"
+            else:
+                assert r[1] == len(stored)
+                stored.append(r[1])
+        assert stored == list(range(tiles))
+
+
+def _persist_tiles(mt, nt, planes, G):
+    """host + device tile walk of gemm_split3_persist_kernel: returns, per block, the (z, tile_m, tile_n) it visits, in order"""
+    total = mt * nt * planes
+    gm = 32 // nt if nt <= 6 else 8
+    per_plane, per_group = mt * nt, gm * nt
+    out = []
+    for b in range(G):
+        xcd, nb = b & 7, (G - (b & 7) + 7) >> 3
+        lo, hi = total * xcd // 8, total * (xcd + 1) // 8
+        seq = []
+        l = lo + (b >> 3)
+        while l < hi:
+            z, r = divmod(l, per_plane)
+            group, in_g = divmod(r, per_group)
+            first = group * gm
+            gsz = min(mt - first, gm)
+            tn = in_g // gsz
+            seq.append((z, first + in_g - tn * gsz, tn))
+            l += nb
+        out.append(seq)
+    return out
+
+
+@pytest.mark.parametrize("mt,nt,planes,G", [(797, 5, 36, 256), (65, 24, 1, 256), (65, 8, 1, 256), (9, 5, 1, 16), (8, 2, 5, 40), (5, 2, 3, 8), (17, 1, 1, 8),
+                                            (259, 6, 36, 256), (65, 32, 1, 248), (3, 7, 2, 24)])
+def test_persistent_tile_walk_covers_every_tile_once(mt, nt, planes, G):
+    walks = _persist_tiles(mt, nt, planes, G)
+    seen = [t for w in walks for t in w]
+    assert len(seen) == mt * nt * planes == len(set(seen))
+    assert all(0 <= z < planes and 0 <= m < mt and 0 <= n < nt for z, m, n in seen)
+    lens = [len(w) for w in walks]
+    assert max(lens) - min(lens) <= 1 + (1 if (mt * nt * planes) % 8 else 0), lens     # balanced to within a tile (plus the XCD range rounding)

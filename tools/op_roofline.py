@@ -4,7 +4,11 @@ Runs the bench workload (Depth-Anything ViT-L, 2160x3840, 4x4 tiles, process_num
 every HipOps entry point, keeps the first occurrence of every distinct (op, shapes, dtypes, strides, scalars) call with
 its real argument tensors, then times each distinct call standalone (torch.cuda events on the launch stream; the
 kernels are launched on torch's current stream) and prices it against the roofline that bounds it:
-  * conv / linear / attention  -> algorithmic FLOPs / time  vs the dense MFMA peak of the dtype (2.5 PF/s bf16, 157.3 TF/s f32)
+  * conv / linear / attention  -> the launch's OWN useful multiply-adds / time  vs the peak of the pipe it EXECUTES on: the f32 MFMA
+                                  (157.3 TF/s) for the f32-MFMA kernels, 2500 / 6 = 416.7 TF/s for the split-precision kernels (six bf16 MFMAs
+                                  per float32-grade product), 2.5 PF/s in bf16 mode.  Winograd layers are priced on their transform-domain
+                                  multiply-adds (a quarter of the direct convolution's) over the WHOLE layer time (transforms included); the
+                                  direct-convolution equivalent is printed beside it.  No row can exceed 100 %.
   * everything else            -> algorithmic bytes (every logical input element read once + every output element
                                   written once; ROI ops: only the ROI region of the source) / time  vs 8 TB/s HBM
 
@@ -30,6 +34,7 @@ from patchfusion_amd.spec import patchfusion_spec, synthetic_state_dict  # noqa:
 
 HBM_PEAK = 8.0e12
 MFMA_PEAK = {"bf16": 2500e12, "fp32": 157.3e12}
+SPLIT_PEAK = 2500e12 / 6.0          # float32-grade products per second on the bf16 MFMA (six instructions per product)
 
 
 def _as4(t):
@@ -72,14 +77,19 @@ def work(name, a, k):
         from patchfusion_amd import hip_ops
         fused = wino and pw.wino_up is not None and hip_ops._fused_wanted(x4.shape[0], x4.shape[1], x4.shape[2], pw)
         tag = ""
+        desc = f"{tuple(x4.shape[:3])} {pw.cin}->{pw.cout} k{pw.KH} s{k.get('stride', 1)}" + (" convT" if s > 1 else "")
         if wino and (fused or pw.wino_u is not None):
-            tag = (f" [winograd F{pw.wino_m} FUSED kernel, rate = direct-conv FLOPs / time]" if fused else
-                   f" [winograd F{pw.wino_m}: 3 steps{', split-precision GEMM' if hip_ops._split3_three_step(pw) else ''}, rate = direct-conv FLOPs / time]")
-        return "flop", fl, f"{tuple(x4.shape[:3])} {pw.cin}->{pw.cout} k{pw.KH} s{k.get('stride', 1)}" + (" convT" if s > 1 else "") + tag
+            m = pw.wino_m
+            own = fl * (m + 2) ** 2 / (9.0 * m * m)          # the layer's own multiply-adds in the transform domain (tile padding not counted)
+            split = (not fused) and m == 4 and hip_ops._split3_three_step(pw)
+            tag = (f" [winograd F{m} FUSED kernel, f32 MFMA]" if fused else
+                   f" [winograd F{m}: 3 steps, {'split-precision GEMM on the bf16 MFMA' if split else 'f32 MFMA GEMM'}; time incl. transforms]")
+            return "flop", own, desc + tag + f" (direct-conv equivalent x{fl / own:.2f})", (SPLIT_PEAK if split else None)
+        return "flop", fl, desc
     if name == "conv_split3":
         x3, pw, y = a[0], a[1], a[2]
         fl = 2.0 * x3.shape[1] * pw.cin * pw.cout
-        return "flop", fl, (f"(1, 1, {x3.shape[1]}) {pw.cin}->{pw.cout} k1 s1 [split-precision bf16x3: USEFUL f32 FLOPs / time vs the f32 MFMA peak; 6x bf16 FLOPs executed]" + (" -> planes" if y.dtype == torch.bfloat16 else ""))
+        return "flop", fl, (f"(1, 1, {x3.shape[1]}) {pw.cin}->{pw.cout} k1 s1 [split-precision bf16x3]" + (" -> planes" if y.dtype == torch.bfloat16 else "")), SPLIT_PEAK
     if name == "layernorm_split3":
         x, y3 = a[0], a[1]
         return "byte", nbytes(x) + nbytes(y3), f"rows {x.shape[0]} D{x.shape[1]} -> three bf16 planes"
@@ -87,6 +97,8 @@ def work(name, a, k):
         return "byte", nbytes(a[0]) + nbytes(a[1]), f"{tuple(a[0].shape)} -> three bf16 planes"
     if name == "vit_attention":
         qkv, out, B, S, heads = a[:5]
+        if qkv.dim() == 3:
+            return "flop", 4.0 * B * heads * S * S * 64, f"B{B} S{S} heads{heads} [split-precision bf16x3, planes in / out]", SPLIT_PEAK
         return "flop", 4.0 * B * heads * S * S * 64, f"B{B} S{S} heads{heads}" + (" (reads the QKV rows, no split)" if qkv.dtype == torch.float32 else " (incl. qkv_split)") + \
             (" -> planes" if qkv.dtype == torch.float32 and out.dtype == torch.bfloat16 else "")
     if name == "swin_window_attention":
@@ -228,10 +240,12 @@ def main():
             e1.record()
             e1.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / iters
-        kind, amount, desc = w
+        kind, amount, desc = w[:3]
+        peak = (w[3] if len(w) > 3 and w[3] else MFMA_PEAK[dtype]) if kind == "flop" else HBM_PEAK
         rate = amount / (us * 1e-6)
-        frac = rate / (MFMA_PEAK[dtype] if kind == "flop" else HBM_PEAK)
-        rows.append(dict(op=n, shape=desc, launches=calls[key], us=us, kind=kind, amount=amount, rate=rate, frac=frac, total_ms=calls[key] * us / 1e3))
+        frac = rate / peak
+        rows.append(dict(op=n, shape=desc, launches=calls[key], us=us, kind=kind, amount=amount, rate=rate, peak=peak, frac=frac,
+                         total_ms=calls[key] * us / 1e3))
     rows.sort(key=lambda r: -r["total_ms"])
     tot = sum(r["total_ms"] for r in rows)
     by_op = collections.defaultdict(float)
@@ -239,16 +253,18 @@ def main():
         by_op[(r["op"], r["kind"])] += r["total_ms"]
     out = [f"# every kernel launch of one 4K image pass (ViT-L, P=16, process_num=8, {dtype}), each distinct call timed standalone", "",
            f"sum of standalone times: {tot:.1f} ms per image; {sum(r['launches'] for r in rows)} launches, {len(rows)} distinct (op, shape) calls.",
-           f"MFMA-bound rows: TFLOP/s vs {MFMA_PEAK[dtype] / 1e12:.1f} TF/s dense peak; HBM-bound rows: algorithmic GB/s vs 8000 GB/s.",
-           "Rows tagged [winograd Fm ...] run the float32 Winograd layer (fused kernel csrc/wino_fused.hip, or the three steps of csrc/winograd.hip): their rate is the DIRECT convolution's "
-           "FLOPs over the layer time, so it can exceed the MFMA peak (the layer multiplies (m+2)^2 / (9 m^2) as often).", "",
+           f"MFMA-bound rows: the launch's own useful TFLOP/s vs the peak of the pipe it executes on ({MFMA_PEAK[dtype] / 1e12:.1f} TF/s; split-precision rows "
+           f"[bf16x3]: {SPLIT_PEAK / 1e12:.1f} TF/s = the bf16 MFMA peak / 6); HBM-bound rows: algorithmic GB/s vs 8000 GB/s.",
+           "Rows tagged [winograd Fm ...] run the float32 Winograd layer (fused kernel csrc/wino_fused.hip, or the three steps of csrc/winograd.hip): priced on the layer's own "
+           "transform-domain multiply-adds over the whole layer time; multiply by the printed factor for the direct-convolution equivalent.", "",
            "## per op", "", "| op | bound | total ms / image | share |", "|---|---|---:|---:|"]
     for (op, kind), t in sorted(by_op.items(), key=lambda kv: -kv[1]):
         out.append(f"| {op} | {'MFMA' if kind == 'flop' else 'HBM'} | {t:.2f} | {100 * t / tot:.1f}% |")
-    out += ["", "## per (op, shape)", "", "| op | shape | launches | us / launch | rate | % of roofline | total ms |", "|---|---|---:|---:|---:|---:|---:|"]
+    out += ["", "## per (op, shape)", "", "| op | shape | launches | us / launch | rate | peak of its pipe | % of roofline | total ms |", "|---|---|---:|---:|---:|---:|---:|---:|"]
     for r in rows:
         rate = f"{r['rate'] / 1e12:.1f} TF/s" if r["kind"] == "flop" else f"{r['rate'] / 1e9:.0f} GB/s"
-        out.append(f"| {r['op']} | {r['shape']} | {r['launches']} | {r['us']:.1f} | {rate} | {100 * r['frac']:.1f} | {r['total_ms']:.3f} |")
+        pk = f"{r['peak'] / 1e12:.1f} TF/s" if r["kind"] == "flop" else "8000 GB/s"
+        out.append(f"| {r['op']} | {r['shape']} | {r['launches']} | {r['us']:.1f} | {rate} | {pk} | {100 * r['frac']:.1f} | {r['total_ms']:.3f} |")
     txt = "\n".join(out) + "\n"
     if len(sys.argv) > 2:
         open(sys.argv[2], "w").write(txt)

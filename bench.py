@@ -302,7 +302,7 @@ def roofline(dtype, dev, gemm_only=False):
         # priced as its USEFUL float32 multiply-adds 36 * 2 * T * C * C against the f32 MFMA peak -- the roofline of the arithmetic the layer
         # asks for -- with the executed bf16 rate against the bf16 peak beside it.
         T = B * -(-H // 4) * -(-W // 4)
-        V3 = torch.randn(3, 36, T, C, device=dev).to(torch.bfloat16)
+        V3 = torch.randn(3, 36, C // 32, T, 32, device=dev).to(torch.bfloat16)       # chunk-major planes, as the input transform writes them
         Mw = torch.empty(36 * T * C, device=dev)
         ms = ops.gemm_planes_split3_timed(V3, pw.wino_u3, Mw.view(36, T, C), T, C, C, 5)
         flops = 36 * 2.0 * T * C * C

@@ -74,8 +74,9 @@ int pf_conv_timed(const pf_conv_params* p, int iters, float* ms, void* stream);
  * m = 2 multiplies 2.25x less than the direct convolution at ~2.5x its float32 rounding error, m = 4 4x less at ~15x. */
 int pf_conv_winograd(const pf_conv_params* p, int m, const void* U, int u_rows, int u_kpad, void* V, void* M, void* stream);
 /* The same three steps with the transform-domain GEMM in split precision (m = 4): V3 = workspace of 3 x 36 x T x Cin bf16 (the input transform
- * writes the three planes), U3 = packing.winograd_filters_split3 ([3][36][u_rows][u_kpad] bf16), M = 36 x T x Cout float32; one batched
- * pf_gemm_split3 launch between the transforms. */
+ * writes the three planes, chunk-major: [3][36][Cin/32][T][32]), U3 = the three bf16 planes of G g G^T, chunk-major [3][36][Cin/32][u_rows][32]
+ * (patchfusion_amd/packing.py PackedConv.wino_u3; u_kpad must equal Cin), M = 36 x T x Cout float32; one batched pf_gemm_split3 launch
+ * (korder = 6) between the transforms. */
 int pf_conv_winograd_split3(const pf_conv_params* p, const void* U3, int u_rows, int u_kpad, void* V3, void* M, void* stream);
 
 /* FUSED Winograd F(4x4, 3x3) (csrc/wino_fused.hip): the same layers in ONE kernel -- the transformed input and the transform-domain
@@ -94,7 +95,11 @@ int pf_conv_winograd_fused_timed(const pf_conv_params* p, const void* up, int nn
  * nearest splits) and the six leading partial products are accumulated in float32.  `p` as for pf_conv with KH = KW = 1: x = planes
  * [3][M][x_ld] bf16 (plane stride x_bstride elements), w = planes [3][w_rows][Kpad] bf16 (w_bstride; packing.pack_conv_split3), Cin % 32
  * == 0, bias / scale / res / res2 float32; y = float32 [M][y_ld] when out_f32 != 0, else three bf16 planes [3][M][y_ld] (y_bstride) for a
- * following split GEMM.  Same reference layers as pf_conv's linear use (attention.py:51,60, mlp.py:35-41). */
+ * following split GEMM.  Same reference layers as pf_conv's linear use (attention.py:51,60, mlp.py:35-41).
+ * p->korder here selects the OPERAND layout: bit 1 (value 2) = every x plane is chunk-major [Cin/32][M][32] (x_ld must equal Cin), bit 2
+ * (value 4) = every w plane is chunk-major [Cin/32][w_rows][32] (Kpad must equal Cin): each 32-deep K chunk of all rows is one contiguous
+ * slab, which is what the kernel's 1-KiB LDS-DMA pieces want (whole cache lines).  p->batch > 1: that many independent planes in one launch
+ * (block k of every x / w plane, float32 output block k, no epilogue) -- the transform points of pf_conv_winograd_split3. */
 int pf_gemm_split3(const pf_conv_params* p, void* stream);
 int pf_gemm_split3_timed(const pf_conv_params* p, int iters, float* ms, void* stream);
 /* A plain bf16 linear layer (x [M][x_ld] bf16, w from packing.pack_conv, bf16 residuals / output, float32 output when out_f32) through the same

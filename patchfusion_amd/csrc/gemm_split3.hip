@@ -13,6 +13,11 @@
 //   D[n][m] = sum_k W[n][k] X[m][k]      n = output channel, m = token; MFMA A = weight rows, B = token rows (a lane's four accumulator
 //                                         registers = four consecutive channels of one token, as in igemm.hip)
 // Operands: X planes [3][M][x_ld] bf16 (plane stride x_bstride elements), W planes [3][w_rows][Kpad] (w_bstride), K = Cin % 32 == 0.
+// CHUNK-MAJOR operands (round 4; p.korder bit 1 = X, bit 2 = W): a plane is stored as [K/32][rows][32] -- every 32-deep K chunk of all rows is one
+// contiguous slab, so the 16 rows x 64 B of a DMA piece are ONE contiguous KiB (eight full 128-byte lines).  In the row-major layout a piece
+// touches 16 lines and uses half of each; the other half is fetched again one chunk later, after 48 KiB of other traffic went through the 32-KiB
+// vector L1: the L2 -> L1 traffic of the kernel is twice its operand bytes, and that stream -- not the matrix pipe -- bounds it
+// (profiles/r4_persist_decomp.md: DMA stream alone 9.3 ms, MFMA stream alone 7.8 ms, full kernel 12.2 ms on the dominant launch).
 // Output: float32 [M][y_ld] (out_f32 = 1) or, for a following split GEMM (fc1 -> fc2), three bf16 planes [3][M][y_ld] (y_bstride).
 // Epilogue in float32 exactly like pf_conv: (act(v + bias) * scale) + res + res2.
 //
@@ -96,15 +101,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split3_kernel(const pf_conv
     const int row = (wave * PPW + i) * 16 + (lane >> 2);        // row of the stage: [X plane 0..2 | W plane 0..2]
     const int j = (lane & 3) ^ ((row >> 1) & 3);
     const char* src = zero;
+    int step = PLAIN ? 64 * NP : 64;
     if (row < NP * BM) {
       const int pl = row / BM, m = m0 + (row - pl * BM);
-      if (m < M) src = reinterpret_cast<const char*>(xg + (size_t)pl * p.x_bstride + (size_t)m * p.x_ld + j * 8);
+      if (m < M) src = reinterpret_cast<const char*>(xg + (size_t)pl * p.x_bstride + (size_t)m * ((p.korder & 2) ? 32 : p.x_ld) + j * 8);
+      if (p.korder & 2) step = M * 64;                  // chunk-major: the next K chunk of this row is one [M][32] slab further
     } else {
       const int rw = row - NP * BM, pl = rw / BN, n = n0 + (rw - pl * BN);
-      if (n < p.w_rows) src = reinterpret_cast<const char*>(wg + (size_t)pl * p.w_bstride + (size_t)n * p.Kpad + j * 8);
+      if (n < p.w_rows) src = reinterpret_cast<const char*>(wg + (size_t)pl * p.w_bstride + (size_t)n * ((p.korder & 4) ? 32 : p.Kpad) + j * 8);
+      if (p.korder & 4) step = p.w_rows * 64;
     }
     cur[i] = src;
-    inc[i] = src == zero ? 0 : (PLAIN ? 64 * NP : 64);
+    inc[i] = src == zero ? 0 : step;
   }
   const unsigned smem_base = lds_addr(smem);
 #ifdef PF_S3_DBG           // timing decomposition (results wrong by construction): env PF_S3_DBG bit 0 = no DMA after the first ring fill,
@@ -363,11 +371,13 @@ __global__ __launch_bounds__(512) void gemm_split3_persist_kernel(const pf_conv_
   // ---- loader: wave w moves pieces w*PPW .. +PPW-1 of a stage [X h | X m | X l | W h | W m | W l]; lane L -> row 16 q + (L >> 2),
   // physical slot L & 3 = logical slot ^ ((row >> 1) & 3)
   const bool is_x = wave < WM;
-  const int ld_b = (is_x ? p.x_ld : p.Kpad) * 2;                              // operand row pitch in bytes
+  const bool kmaj = (p.korder & (is_x ? 2 : 4)) != 0;                         // chunk-major operand: [K/32][rows][32]
   const int lim = is_x ? M : p.w_rows;
+  const int ld_b = kmaj ? 64 : (is_x ? p.x_ld : p.Kpad) * 2;                  // operand row pitch in bytes
+  const unsigned adv_b = kmaj ? (unsigned)lim * 64u : 64u;                    // from one K chunk to the next
   const unsigned long long op_base = is_x ? (unsigned long long)p.x : (unsigned long long)p.w;
   const unsigned long long pl_b = (unsigned long long)(is_x ? p.x_bstride : p.w_bstride) * 2;   // h / m / l plane pitch in bytes
-  const unsigned long long z_b = (unsigned long long)lim * ld_b;              // transform-point pitch (batched) in bytes
+  const unsigned long long z_b = (unsigned long long)lim * ((is_x ? p.x_ld : p.Kpad) * 2);      // transform-point pitch (batched) in bytes
   unsigned long long sbase[PPW];
   unsigned voff[PPW];
   auto setup_loader = [&](int l) __attribute__((always_inline)) {
@@ -388,13 +398,24 @@ __global__ __launch_bounds__(512) void gemm_split3_persist_kernel(const pf_conv_
   const unsigned smem_base = lds_addr(smem);
   int l_load = l_first, l_kc = 0, s_issue = 0;
   setup_loader(l_load);
+#ifdef PF_S3_DBG           // timing decomposition (results wrong by construction): p.pad bit 0 = no DMA after the first ring fill, bit 1 = no MFMA,
+  const int dbg = p.pad;   // bit 2 = no fragment reads after the first, bit 3 = no epilogue stores
+  int dbg_issued = 0, dbg_reads = 0;
+#define S3P_DBG(bit) (dbg & (bit))
+#else
+#define S3P_DBG(bit) 0
+#endif
   auto issue = [&]() __attribute__((always_inline)) {
+#ifdef PF_S3_DBG
+    if (S3P_DBG(1) && dbg_issued >= NS) return;
+    ++dbg_issued;
+#endif
     // (readfirstlane: the ring position is wave-uniform by construction, but hipcc's divergence analysis loses that through the tile walk)
     const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + s_issue * STAGE + wave * (PPW * 1024));
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       glds16s(voff[i], sbase[i], dst + i * 1024);
-      sbase[i] += 64;
+      sbase[i] += adv_b;
     }
     s_issue = s_issue == NS - 1 ? 0 : s_issue + 1;
     if (++l_kc == nk) {                                  // the stream moves on to this block's next tile
@@ -417,6 +438,9 @@ __global__ __launch_bounds__(512) void gemm_split3_persist_kernel(const pf_conv_
   struct Frags { uint4 w[NP][FN], x[NP][FM]; };
   int s_read = 0;
   auto read_frags = [&](Frags& f) __attribute__((always_inline)) {
+#ifdef PF_S3_DBG
+    if (S3P_DBG(4) && dbg_reads++ >= 2) return;
+#endif
     const char* S = smem + s_read * STAGE;
     s_read = s_read == NS - 1 ? 0 : s_read + 1;
 #pragma unroll
@@ -428,6 +452,7 @@ __global__ __launch_bounds__(512) void gemm_split3_persist_kernel(const pf_conv_
     }
   };
   auto multiply = [&](const Frags& f) __attribute__((always_inline)) {
+    if (S3P_DBG(2)) return;
 #define S3_TERM(PW, PX)                                                                                                      \
   _Pragma("unroll") for (int fn = 0; fn < FN; ++fn) _Pragma("unroll") for (int fm = 0; fm < FM; ++fm)                       \
       acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.w[PW][fn]), __builtin_bit_cast(bf16x8, f.x[PX][fm]), \
@@ -459,7 +484,7 @@ __global__ __launch_bounds__(512) void gemm_split3_persist_kernel(const pf_conv_
 #pragma unroll
       for (int fm = 0; fm < FM; ++fm) {
         const int m = e_m0 + wm * WTM + fm * 16 + fr;
-        if (m < M && n < p.Cout) {
+        if (m < M && n < p.Cout && !S3P_DBG(8)) {
           if constexpr (BARE) {
             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + y_base + (long)m * p.y_ld + n) = acc[fn][fm];
           } else {
@@ -508,23 +533,46 @@ __global__ __launch_bounds__(512) void gemm_split3_persist_kernel(const pf_conv_
   if (grp_b) plain_barrier();                           // one phase behind
   // phase M(g): [stores of the tile that ended with chunk g-1], DMA of chunk g+3, fragments of chunk g+1, wait for this wave's pieces of g+2;
   // phase C(g): the 48 MFMAs of chunk g out of registers
+#ifdef PF_S3_DBG
+  // timeline build (tools/persist_probe.py timeline): waves 0 and 4 of block 0 stamp s_memtime at the seams of chunks 64 .. 95 into p.res2
+  // (8 stamps per chunk and wave: phase start, after the epilogue branch, after the DMA issue, after the fragment reads were issued, after the
+  // vmcnt wait, after the LDS barrier, after the MFMAs, after the closing barrier)
+  unsigned long long* tl = BARE ? nullptr : nullptr;
+  if constexpr (BARE) tl = reinterpret_cast<unsigned long long*>(const_cast<void*>(p.res2));
+  const bool stamp_w = tl && blockIdx.x == 0 && (wave == 0 || wave == 4);
+#define S3_STAMP(g, k)                                                                                      \
+  if (stamp_w && (g) >= 64 && (g) < 96) {                                                                   \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                             \
+    if (lane == 0) tl[(((wave >> 2) * 32 + ((g) - 64)) << 3) + (k)] = t_;                                    \
+  }
+#else
+#define S3_STAMP(g, k)
+#endif
   auto pp_chunk = [&](const Frags& cf, Frags& nf, int g) __attribute__((always_inline)) {
+    S3_STAMP(g, 0)
     if (epi_pending) epilogue();                        // beside the partner group's MFMAs
     if (c_kc == nk - 1) {                               // chunk g ends a tile
       decode(l_comp, e_z, e_m0, e_n0);
       l_comp += nb;
     }
+    S3_STAMP(g, 1)
     if (g + 3 < chunks) issue();
+    S3_STAMP(g, 2)
     if (g + 1 < chunks) read_frags(nf);
+    S3_STAMP(g, 3)
     if (g + 3 < chunks) vm_wait<PPW>();
     else if (g + 2 < chunks) vm_wait<0>();
+    S3_STAMP(g, 4)
     lds_barrier();
+    S3_STAMP(g, 5)
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
     multiply(cf);
     __builtin_amdgcn_s_setprio(0);
+    S3_STAMP(g, 6)
     if (++c_kc == nk) { c_kc = 0; epi_pending = true; }
     plain_barrier();
+    S3_STAMP(g, 7)
   };
 #pragma nounroll
   for (int g = 0; g < chunks; g += 2) {
@@ -570,7 +618,11 @@ int launch_persist(const pf_conv_params& p, hipStream_t st) {
   if (grid > total) grid = (int)total;
   grid &= ~7;
   if (grid < 8 || total > 0x7fffffffL) return PF_ERR_ARG;
+#ifdef PF_S3_DBG
+  const bool bare = !p.bias && !p.scale && !p.res && p.act == PF_ACT_NONE && p.out_f32;          // (res2 = the timeline buffer)
+#else
   const bool bare = !p.bias && !p.scale && !p.res && !p.res2 && p.act == PF_ACT_NONE && p.out_f32;
+#endif
   if (bare) hipLaunchKernelGGL(gemm_split3_persist_kernel<true>, dim3((unsigned)grid), dim3(512), smem, st, p, mt, nt, gm, (int)total);
   else hipLaunchKernelGGL(gemm_split3_persist_kernel<false>, dim3((unsigned)grid), dim3(512), smem, st, p, mt, nt, gm, (int)total);
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_LAUNCH;
@@ -612,7 +664,13 @@ extern "C" int pf_gemm_split3(const pf_conv_params* p, void* stream) {
   else if ((p->res && p->res_ld % 4) || (p->res2 && p->res2_ld % 4)) e = "residual ld must be a multiple of 4";
   else if ((long)p->B * p->OH * p->OW <= 0 || (long)p->B * p->OH * p->OW >= (1L << 31)) e = "bad token count";
   else if (p->x_bstride <= 0 || p->w_bstride <= 0 || (!p->out_f32 && p->y_bstride <= 0)) e = "plane strides missing";
+  else if (((p->korder & 2) && p->x_ld != p->Cin) || ((p->korder & 4) && p->Kpad != p->Cin) || (p->korder & ~6)) e = "chunk-major operands are dense: x_ld == Kpad == Cin";
+  else if ((long)p->B * p->OH * p->OW * 64 >= (1L << 31) || (long)p->w_rows * 64 >= (1L << 31)) e = "too many rows for a chunk-major slab";
+#ifdef PF_S3_DBG
+  else if (p->batch > 1 && (!p->out_f32 || p->bias || p->scale || p->res || p->batch > 65535)) e = "batched planes: float32 output, no epilogue";
+#else
   else if (p->batch > 1 && (!p->out_f32 || p->bias || p->scale || p->res || p->res2 || p->batch > 65535)) e = "batched planes: float32 output, no epilogue";
+#endif
   if (e) return PF_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   // tile: 128 x 128 (eight waves, one block per CU, ping-pong) unless the token x channel grid does not fill the chip once; PF_S3_TILE_NOW forces

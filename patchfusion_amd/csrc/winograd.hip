@@ -54,7 +54,10 @@ template <> struct Wino<4> {
 // one thread = one tile x 4 channels: (m+2)^2 16-byte loads (zero outside the image = the conv's padding), B^T d B in registers,
 // (m+2)^2 16-byte stores into the planes of V.  Consecutive lanes take consecutive channel groups: every load / store of a wave is
 // a contiguous 1 KiB run of one pixel / one V row.
-// SPLIT: V is written as the three bf16 planes of the split-precision GEMM (csrc/gemm_split3.hip): [3][(m+2)^2][T][C] bf16
+// SPLIT: V is written as the three bf16 planes of the split-precision GEMM (csrc/gemm_split3.hip), CHUNK-MAJOR: [3][(m+2)^2][C/32][T][32] bf16
+// (every 32-channel K chunk of all tiles is one slab = what the GEMM's 1-KiB DMA pieces read as whole cache lines).  Thread order for that
+// layout: 8 lanes = the 8 channel quads of one chunk of one tile (64 B of a slab row, 128 B of a pixel), 8 tiles per wave -> every store
+// of a wave is one contiguous 512-byte run of a slab; then the chunks of the same 8 tiles.
 template <int MT, bool SPLIT = false>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int x_ld, int B, int H, int W, int C, int relu_in,
                                                          float* __restrict__ V, int TH, int TW) {
@@ -62,9 +65,19 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
   const int cv = C >> 2;
   const long T = (long)B * TH * TW;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= T * cv) return;
-  const int c4 = (int)(idx % cv);
-  const long tile = idx / cv;
+  int c4;
+  long tile;
+  if constexpr (SPLIT) {
+    const int nkc = C >> 5;                           // C % 32 == 0
+    const long w64 = idx >> 6;                        // (tile octet, chunk) pairs, chunk fastest
+    tile = (w64 / nkc) * 8 + ((idx >> 3) & 7);
+    c4 = (int)(w64 % nkc) * 8 + (int)(idx & 7);
+    if (tile >= T) return;
+  } else {
+    if (idx >= T * cv) return;
+    c4 = (int)(idx % cv);
+    tile = idx / cv;
+  }
   const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((long)TW * TH));
   float d[A][A][4];
 #pragma unroll
@@ -103,7 +116,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
   }
   const size_t plane = (size_t)T * C;
   if constexpr (SPLIT) {
-    bf16_t* o = reinterpret_cast<bf16_t*>(V) + (size_t)tile * C + c4 * 4;
+    bf16_t* o = reinterpret_cast<bf16_t*>(V) + ((size_t)(c4 >> 3) * T + tile) * 32 + (c4 & 7) * 4;
 #pragma unroll
     for (int i = 0; i < A; ++i)
 #pragma unroll
@@ -226,7 +239,7 @@ int run_split3(const pf_conv_params* p, const void* U3, int u_rows, int u_kpad, 
   const int TH = (p->H + MT - 1) / MT, TW = (p->W + MT - 1) / MT;
   const long T = (long)p->B * TH * TW;
   if (T > 0x7fffffffL) return PF_ERR_ARG;
-  const long nin = T * (p->Cin / 4), nout = T * (p->Cout / 4);
+  const long nin = ((T + 7) / 8) * 8 * (p->Cin / 4), nout = T * (p->Cout / 4);       // (input transform: whole tile octets, see the kernel)
   hipLaunchKernelGGL((wino_input_kernel<MT, true>), dim3((unsigned)((nin + 255) / 256)), dim3(256), 0, st, static_cast<const float*>(p->x), p->x_ld,
                      p->B, p->H, p->W, p->Cin, p->relu_in, static_cast<float*>(V3), TH, TW);
   if (launch_ok() != PF_OK) return PF_ERR_LAUNCH;
@@ -236,6 +249,7 @@ int run_split3(const pf_conv_params* p, const void* U3, int u_rows, int u_kpad, 
   q.y_ld = p->Cout; q.OH = 1; q.OW = (int)T; q.Cout = p->Cout;
   q.KH = q.KW = 1; q.stride = 1; q.pad = 0; q.act = PF_ACT_NONE; q.shuffle = 1; q.dtype = PF_DTYPE_BF16; q.out_f32 = 1;
   q.x = V3; q.w = U3; q.y = M;
+  q.korder = 6;                                         // V3 and U3 are chunk-major: [plane][point][Cin/32][rows][32]
   q.batch = A * A;                                      // transform points: x / w / y advance by one [T][Cin] / [rows][Kpad] / [T][Cout] block each
   q.x_bstride = (long)A * A * T * p->Cin;               // h / m / l plane strides
   q.w_bstride = (long)A * A * u_rows * u_kpad;
@@ -254,7 +268,7 @@ extern "C" int pf_conv_winograd_split3(const pf_conv_params* p, const void* U3, 
   if (p->dtype != PF_DTYPE_F32 || p->KH != 3 || p->KW != 3 || p->stride != 1 || p->pad != 1 || p->shuffle > 1 || p->scale) return PF_ERR_ARG;
   if (p->OH != p->H || p->OW != p->W || p->Cin % 32 || p->Cout % 8 || p->Cin <= 0 || p->Cout <= 0) return PF_ERR_ARG;
   if (p->act != PF_ACT_NONE && p->act != PF_ACT_RELU) return PF_ERR_ARG;
-  if (u_rows < p->Cout || u_kpad < p->Cin || u_kpad % 32) return PF_ERR_ARG;
+  if (u_rows < p->Cout || u_kpad != p->Cin) return PF_ERR_ARG;       // (chunk-major planes are dense in K)
   return run_split3(p, U3, u_rows, u_kpad, V3, static_cast<float*>(M), ST(stream));
 }
 

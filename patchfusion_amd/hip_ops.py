@@ -224,7 +224,7 @@ class HipOps:
 
             def run():
                 if split:
-                    check(_L.pf_conv_winograd_split3(C.byref(p), _p(pw.wino_u3), pw.wino_u3.shape[2], pw.wino_u3.shape[3], _p(V), _p(Mw), _stream()),
+                    check(_L.pf_conv_winograd_split3(C.byref(p), _p(pw.wino_u3), pw.wino_u3.shape[3], pw.wino_u3.shape[2] * 32, _p(V), _p(Mw), _stream()),
                           "pf_conv_winograd_split3")
                     return
                 check(_L.pf_conv_winograd(C.byref(p), m, _p(pw.wino_u), pw.wino_u.shape[1], pw.wino_u.shape[2], _p(V), _p(Mw), _stream()),
@@ -246,14 +246,18 @@ class HipOps:
     @staticmethod
     def gemm_planes_split3(V3, U3, Mw, T, cin, cout, iters=None):
         """the batched split-precision GEMM launch of a three-step Winograd layer alone, exactly as csrc/winograd.hip run_split3 issues it:
-        V3 bf16 [3, P, T, cin], U3 bf16 [3, P, rows, Kpad], Mw float32 [P, T, cout] (P = 36 transform points there); iters = None runs it
-        once, else returns the average milliseconds of `iters` launches (HIP events on the launch stream; bench.py roofline)"""
+        CHUNK-MAJOR operands V3 bf16 [3, P, cin/32, T, 32], U3 bf16 [3, P, cin/32, rows, 32] (PackedConv.wino_u3), Mw float32 [P, T, cout]
+        (P = 36 transform points there) -- or both ROW-major, V3 [3, P, T, cin], U3 [3, P, rows, cin] (4-D; tests); iters = None runs it once,
+        else returns the average milliseconds of `iters` launches (HIP events on the launch stream; bench.py roofline)"""
         P = V3.shape[1]
-        assert V3.dtype == U3.dtype == torch.bfloat16 and Mw.dtype == torch.float32 and tuple(V3.shape) == (3, P, T, cin) and U3.shape[:2] == (3, P)
+        kmaj = V3.dim() == 5
+        assert V3.dim() == U3.dim() and V3.dtype == U3.dtype == torch.bfloat16 and Mw.dtype == torch.float32 and U3.shape[:2] == (3, P)
+        assert tuple(V3.shape) == ((3, P, cin // 32, T, 32) if kmaj else (3, P, T, cin)) and (U3.shape[2] * 32 if kmaj else U3.shape[3]) == cin
         assert V3.is_contiguous() and U3.is_contiguous() and Mw.is_contiguous() and Mw.numel() >= P * T * cout
         p = ConvParams()
         p.x, p.x_ld, p.B, p.H, p.W, p.Cin = V3.data_ptr(), cin, 1, 1, T, cin
-        p.w, p.w_rows, p.Kpad = U3.data_ptr(), U3.shape[2], U3.shape[3]
+        p.w, p.w_rows, p.Kpad = U3.data_ptr(), U3.shape[3] if kmaj else U3.shape[2], cin
+        p.korder = 6 if kmaj else 0
         p.y, p.y_ld, p.OH, p.OW, p.Cout = Mw.data_ptr(), cout, 1, T, cout
         p.KH = p.KW = p.stride = 1
         p.act, p.shuffle, p.dtype, p.out_f32, p.batch = 0, 1, 1, 1, P

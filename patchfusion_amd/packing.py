@@ -34,7 +34,7 @@ class PackedConv:
     wino_m: int = 0                 # Winograd F(m x m, 3 x 3) output tile (2 | 4), 0 = direct kernel only
     wino_u: Optional[torch.Tensor] = None   # [(m+2)^2, rows, Kpad1] float32: G g G^T, each plane packed like a 1x1 weight
     wino_up: Optional[torch.Tensor] = None  # m = 4 only: the same filters in the fragment order of the fused kernel (winograd_filters_fused)
-    wino_u3: Optional[torch.Tensor] = None  # m = 4 only: wino_u as the three bf16 planes of the split-precision GEMM, [3, 36, rows, Kpad1]
+    wino_u3: Optional[torch.Tensor] = None  # m = 4 only: wino_u as the three bf16 planes of the split-precision GEMM, chunk-major [3, 36, Kpad1/32, rows, 32]
 
     def to(self, device):
         self.w = self.w.to(device)
@@ -193,7 +193,10 @@ def pack_conv(weight, bias=None, *, dtype, cin_map=None, cin_total=None, scale=N
     wm = winograd_mode() if (scale is None and winograd_eligible(cout_store, cin_total, KH, KW, dtype)) else 0
     wu = winograd_filters(wk, wm) if wm else None
     wup = winograd_filters_fused(wk) if wm == 4 else None
-    wu3 = torch.stack(split3(wu)).contiguous() if (wm == 4 and winograd_split3_enabled()) else None
+    # the three bf16 planes of U for the split-precision GEMM, CHUNK-MAJOR [3, 36, K/32, rows, 32] (csrc/gemm_split3.hip korder bit 2): every
+    # 32-channel chunk of all filter rows is one contiguous slab
+    wu3 = (torch.stack(split3(wu)).view(3, wu.shape[0], wu.shape[1], wu.shape[2] // 32, 32).permute(0, 1, 3, 2, 4).contiguous()
+           if (wm == 4 and winograd_split3_enabled()) else None)
     if wm == 0 and scale is None and winograd_fused_only_eligible(cout_store, cin_total, KH, KW, dtype):
         wm, wup = 4, winograd_filters_fused(wk)                   # fused kernel only (wino_u stays None: no three-step form)
     return PackedConv(wp.to(dtype).contiguous(), bp, sp, KH, KW, cin_total, cout_store, cout, korder=korder, wino_m=wm, wino_u=wu, wino_up=wup, wino_u3=wu3)

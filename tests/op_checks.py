@@ -537,9 +537,20 @@ def gemm_split3_persist(dt):
             y1 = torch.full((P, T, cout), float("nan"), device=DEV)
             o.gemm_planes_split3(V3, U3, y1, T, cin, cout)
             same = same and bool((y1 == y0).all())
+        # chunk-major operands ([plane][point][K/32][rows][32], what csrc/winograd.hip and PackedConv.wino_u3 hand to the kernel): same bits again,
+        # through both kernels
+        V3k = V3.view(3, P, T, cin // 32, 32).permute(0, 1, 3, 2, 4).contiguous()
+        U3k = U3.view(3, P, rows, cin // 32, 32).permute(0, 1, 3, 2, 4).contiguous()
+        for pers, gr in (("0", "0"), ("2", grids[0]), ("2", grids[-1])):
+            os.environ["PF_S3_PERSIST"], os.environ["PF_S3_GRID"] = pers, gr
+            if gr == "0":
+                os.environ.pop("PF_S3_GRID")
+            y1 = torch.full((P, T, cout), float("nan"), device=DEV)
+            o.gemm_planes_split3(V3k, U3k, y1, T, cin, cout)
+            same = same and bool((y1 == y0).all())
         for k in ("PF_S3_TILE_NOW", "PF_S3_PERSIST", "PF_S3_GRID"):
             os.environ.pop(k, None)
-        info.append(f"P{P} T{T} {cin}->{cout}: err {e0:.2e} persistent==one-tile {same}")
+        info.append(f"P{P} T{T} {cin}->{cout}: err {e0:.2e} persistent==one-tile==chunk-major {same}")
         worst = max(worst, e0 if same else float("inf"))
     return worst, 2e-6, "; ".join(info)
 

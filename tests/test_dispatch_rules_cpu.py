@@ -18,8 +18,10 @@ def test_packing_chooses_winograd_filters_by_layer_shape(monkeypatch):
     monkeypatch.delenv("PF_WINO_FUSED_SMALL", raising=False)
     big = _pack(544, 544)                  # three-step eligible: all three filter sets
     assert big.wino_m == 4 and big.wino_u is not None and big.wino_up is not None and big.wino_u3 is not None
-    assert tuple(big.wino_u3.shape) == (3,) + tuple(big.wino_u.shape) and big.wino_u3.dtype == torch.bfloat16
-    assert bool((big.wino_u3.double().sum(0) == big.wino_u.double()).all())          # the planes are an exact split of G g G^T
+    P, rows, K = big.wino_u.shape
+    assert tuple(big.wino_u3.shape) == (3, P, K // 32, rows, 32) and big.wino_u3.dtype == torch.bfloat16      # chunk-major planes
+    u3_rows = big.wino_u3.permute(0, 1, 3, 2, 4).reshape(3, P, rows, K)
+    assert bool((u3_rows.double().sum(0) == big.wino_u.double()).all())          # the planes are an exact split of G g G^T
     small = _pack(32, 64)                  # below the three-step channel threshold: fused filters only
     assert small.wino_m == 4 and small.wino_u is None and small.wino_u3 is None and small.wino_up is not None
     assert _pack(32, 8).wino_m == 0 and _pack(32, 8).wino_up is None                  # Cin < 32: direct kernel

@@ -19,6 +19,7 @@ for st in "$@"; do
   name=${st%%:*}; arg=""; [[ "$st" == *:* ]] && arg=${st#*:}
   log=$O/${TAG}_$(echo "$st" | tr -c 'A-Za-z0-9_\n' '_' | cut -c1-60).log
   case $name in
+    make) ( make -C patchfusion_amd/csrc $arg 2>&1 | tail -3 ) > $log 2>&1 ;;
     env) if [[ -z "${arg#*=}" ]]; then unset "${arg%%=*}"; else export "$arg"; fi; echo "== $st"; continue ;;
     checks) ( timeout 900 python -m pytest tests/test_hip_ops_gpu.py -m gpu -q -x -k "$arg" -s 2>&1 | tail -40 ) > $log 2>&1 ;;
     pytest) ( timeout 2400 python -m pytest tests -m gpu -q -x --durations=8 2>&1 | tail -20 ) > $log 2>&1 ;;

@@ -34,9 +34,12 @@ def wino():
         U3 = (torch.randn(3, 36, rows, cin, device=DEV, generator=g) / cin ** 0.5).to(torch.bfloat16)
         Mw = torch.empty(36, T, cout, device=DEV)
         t0, t1 = timed(lambda: ops.gemm_planes_split3(V3, U3, Mw, T, cin, cout, 5))
+        V3k, U3k = V3.view(3, 36, cin // 32, T, 32), U3.view(3, 36, cin // 32, rows, 32)       # (random data: a reinterpretation is as good as a permute)
+        k0, k1 = timed(lambda: ops.gemm_planes_split3(V3k, U3k, Mw, T, cin, cout, 5))
         fl = 36 * 2.0 * T * cin * cout
         pad = (-(-cout // 128) * 128) / cout
-        print(f"| {cin}->{cout} @ {B}x{H}x{W} | {T} | {t0:.3f} | {t1:.3f} | {t0 / t1:.2f}x | {fl / t1 / 1e9:.1f} | {6 * fl * pad / t1 / 1e9:.0f} | {fl / t1 / 1e9 / (2500 / 6):.3f} |")
+        print(f"| {cin}->{cout} @ {B}x{H}x{W} | {T} | {t0:.3f} | {t1:.3f} | {t0 / t1:.2f}x | {fl / t1 / 1e9:.1f} | {6 * fl * pad / t1 / 1e9:.0f} | {fl / t1 / 1e9 / (2500 / 6):.3f} |"
+              f" chunk-major: {k0:.3f} | {k1:.3f} | {fl / k1 / 1e9:.1f} TF/s | {fl / k1 / 1e9 / (2500 / 6):.3f} |")
         del V3, U3, Mw
         torch.cuda.empty_cache()
 
@@ -60,9 +63,101 @@ def vit():
             print(f"| {name} {K}->{N}{' gelu' if act else ''}{' +res*ls' if res else ''}{' planes out' if split_out else ''} | {M} | {t0:.3f} | {t1:.3f} | {t0 / t1:.2f}x | {fl / t1 / 1e9:.1f} | {fl / t1 / 1e9 / (2500 / 6):.3f} |")
 
 
+def sustain():
+    """is the dominant launch power-limited in steady state?  the same launch timed over 5 / 40 / 160 back-to-back iterations, one-tile vs
+    persistent kernel, random vs all-zero operands (zeros toggle no multiplier inputs: the clock stays high)"""
+    cin = cout = 544
+    T = 8 * 98 * 130
+    g = torch.Generator(device=DEV).manual_seed(0)
+    rows = -(-cout // 16) * 16
+    Mw = torch.empty(36, T, cout, device=DEV)
+    print("\n| operands | kernel | ms/launch over 5 | over 40 | over 160 |")
+    print("|---|---|---|---|---|")
+    for data in ("random", "zeros"):
+        if data == "random":
+            V3 = torch.randn(3, 36, T, cin, device=DEV, generator=g, dtype=torch.float32).to(torch.bfloat16)
+            U3 = (torch.randn(3, 36, rows, cin, device=DEV, generator=g) / cin ** 0.5).to(torch.bfloat16)
+        else:
+            V3 = torch.zeros(3, 36, T, cin, device=DEV, dtype=torch.bfloat16)
+            U3 = torch.zeros(3, 36, rows, cin, device=DEV, dtype=torch.bfloat16)
+        for mode, name in (("0", "one tile per block"), ("1", "persistent")):
+            os.environ["PF_S3_PERSIST"] = mode
+            ts = [ops.gemm_planes_split3(V3, U3, Mw, T, cin, cout, n) for n in (5, 40, 160)]
+            print(f"| {data} | {name} | {ts[0]:.3f} | {ts[1]:.3f} | {ts[2]:.3f} |")
+        del V3, U3
+    os.environ.pop("PF_S3_PERSIST", None)
+
+
+def decomp():
+    """timing decomposition of the persistent kernel on the dominant launch (debug build: PF_LIB_PATH=patchfusion_amd/libpf_wfdbg.so; results are
+    wrong by construction): PF_S3_DBG bit 0 = no DMA after the ring fill, bit 1 = no MFMA, bit 2 = no fragment reads, bit 3 = no stores"""
+    cin = cout = 544
+    T = 8 * 98 * 130
+    g = torch.Generator(device=DEV).manual_seed(0)
+    rows = -(-cout // 16) * 16
+    V3 = torch.randn(3, 36, T, cin, device=DEV, generator=g, dtype=torch.float32).to(torch.bfloat16)
+    U3 = (torch.randn(3, 36, rows, cin, device=DEV, generator=g) / cin ** 0.5).to(torch.bfloat16)
+    Mw = torch.empty(36, T, cout, device=DEV)
+    V3, U3 = V3.view(3, 36, cin // 32, T, 32), U3.view(3, 36, cin // 32, rows, 32)          # chunk-major (the layout the layer uses)
+    print("\n| PF_S3_DBG | what is removed | ms |")
+    print("|---|---|---|")
+    names = {0: "nothing (full kernel)", 1: "DMA", 2: "MFMA", 4: "fragment reads", 8: "stores", 3: "DMA + MFMA", 5: "DMA + reads", 6: "MFMA + reads",
+             7: "DMA + MFMA + reads", 9: "DMA + stores", 13: "DMA + reads + stores (MFMA stream alone)", 15: "everything (tile walk + barriers only)",
+             14: "MFMA + reads + stores (DMA stream alone)", 11: "DMA + MFMA + stores (fragment reads alone)"}
+    for d, nm in names.items():
+        os.environ["PF_S3_DBG"] = str(d)
+        t = ops.gemm_planes_split3(V3, U3, Mw, T, cin, cout, 5)
+        print(f"| {d} | {nm} | {t:.3f} |")
+    os.environ.pop("PF_S3_DBG", None)
+
+
+def timeline():
+    """s_memtime stamps of the persistent kernel's phases (debug build: PF_LIB_PATH=patchfusion_amd/libpf_wfdbg.so), dominant launch, block 0,
+    waves 0 (group A) and 4 (group B), stream chunks 64 .. 95: where a chunk's ~2600 cycles go"""
+    import ctypes as C
+    from patchfusion_amd import _lib
+    from patchfusion_amd.hip_ops import _L, _stream
+    cin = cout = 544
+    T = 8 * 98 * 130
+    g = torch.Generator(device=DEV).manual_seed(0)
+    rows = -(-cout // 16) * 16
+    V3 = torch.randn(3, 36, T, cin, device=DEV, generator=g, dtype=torch.float32).to(torch.bfloat16)
+    U3 = (torch.randn(3, 36, rows, cin, device=DEV, generator=g) / cin ** 0.5).to(torch.bfloat16)
+    Mw = torch.empty(36, T, cout, device=DEV)
+    tl = torch.zeros(2 * 32 * 8, dtype=torch.int64, device=DEV)
+    p = _lib.ConvParams()
+    p.x, p.x_ld, p.B, p.H, p.W, p.Cin = V3.data_ptr(), cin, 1, 1, T, cin
+    p.w, p.w_rows, p.Kpad = U3.data_ptr(), rows, cin
+    p.y, p.y_ld, p.OH, p.OW, p.Cout = Mw.data_ptr(), cout, 1, T, cout
+    p.KH = p.KW = p.stride = 1
+    p.act, p.shuffle, p.dtype, p.out_f32, p.batch = 0, 1, 1, 1, 36
+    p.x_bstride, p.w_bstride = V3.stride(0), U3.stride(0)
+    p.res2 = tl.data_ptr()
+    for _ in range(2):
+        _lib.check(_L.pf_gemm_split3(C.byref(p), _stream()), "pf_gemm_split3")
+    torch.cuda.synchronize()
+    t = tl.cpu().view(2, 32, 8)
+    names = ["epilogue/decode", "DMA issue (6 pieces)", "fragment reads issued", "vmcnt wait", "lgkmcnt(0) + barrier", "48 MFMAs", "closing barrier"]
+    print("\n| wave group | " + " | ".join(names) + " | chunk total |")
+    print("|---|" + "---|" * (len(names) + 1))
+    for grp in range(2):
+        d = (t[grp, :, 1:] - t[grp, :, :-1]).double()
+        tot = (t[grp, 1:, 0] - t[grp, :-1, 0]).double()
+        print(f"| {'AB'[grp]} mean of 32 chunks | " + " | ".join(f"{float(d[:, i].mean()):.0f}" for i in range(7)) + f" | {float(tot.mean()):.0f} |")
+        print(f"| {'AB'[grp]} median | " + " | ".join(f"{float(d[:, i].median()):.0f}" for i in range(7)) + f" | {float(tot.median()):.0f} |")
+        print(f"| {'AB'[grp]} max | " + " | ".join(f"{float(d[:, i].max()):.0f}" for i in range(7)) + f" | {float(tot.max()):.0f} |")
+    print("(s_memtime ticks = shader clock cycles; the instrumentation itself costs ~10 % of a chunk)")
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["wino", "vit"]
     if "wino" in what:
         wino()
     if "vit" in what:
         vit()
+    if "sustain" in what:
+        sustain()
+    if "timeline" in what:
+        timeline()
+    if "decomp" in what:
+        decomp()

@@ -98,7 +98,8 @@ int pf_conv_winograd_fused_timed(const pf_conv_params* p, const void* up, int nn
  * following split GEMM.  Same reference layers as pf_conv's linear use (attention.py:51,60, mlp.py:35-41).
  * p->korder here selects the OPERAND layout: bit 1 (value 2) = every x plane is chunk-major [Cin/32][M][32] (x_ld must equal Cin), bit 2
  * (value 4) = every w plane is chunk-major [Cin/32][w_rows][32] (Kpad must equal Cin): each 32-deep K chunk of all rows is one contiguous
- * slab, which is what the kernel's 1-KiB LDS-DMA pieces want (whole cache lines).  p->batch > 1: that many independent planes in one launch
+ * slab, which is what the kernel's 1-KiB LDS-DMA pieces want (whole cache lines); bit 3 (value 8) = the three-plane OUTPUT (out_f32 == 0) is
+ * written chunk-major [Cout/32][M][32] (y_ld must equal Cout, Cout % 32 == 0) for a following split GEMM.  p->batch > 1: that many independent planes in one launch
  * (block k of every x / w plane, float32 output block k, no epilogue) -- the transform points of pf_conv_winograd_split3. */
 int pf_gemm_split3(const pf_conv_params* p, void* stream);
 int pf_gemm_split3_timed(const pf_conv_params* p, int iters, float* ms, void* stream);
@@ -106,14 +107,16 @@ int pf_gemm_split3_timed(const pf_conv_params* p, int iters, float* ms, void* st
  * ping-pong LDS-DMA pipeline: 256 x 128 tiles, Cin % 64 == 0.  The bf16 mode's ViT block linears at large token counts (same reference layers). */
 int pf_gemm_bf16_pp(const pf_conv_params* p, void* stream);
 /* the split producers of the ViT block: LayerNorm (layers/block.py:88-93 norm1 / norm2) and the attention output (attention.py:58-60)
- * written as three bf16 planes; arguments as pf_layernorm (plain row range) / pf_vit_attention_qkv with the plane stride in elements */
-int pf_layernorm_split3(const float* x, int x_ld, void* y3, int y_ld, long plane, const float* g, const float* b, float eps, long rows,
-                        int D, void* stream);
-int pf_vit_attention_qkv_split3(const void* qkv, void* out3, long plane, int B, int S, int Hh, void* stream);
+ * written as three bf16 planes; arguments as pf_layernorm (plain row range) / pf_vit_attention_qkv with the plane stride in elements.
+ * kmajor != 0: every output plane is CHUNK-MAJOR [cols/32][rows][32] (rows = all rows of the call), the layout pf_gemm_split3 reads with
+ * korder bit 1; kmajor == 0: row-major [rows][ld]. */
+int pf_layernorm_split3(const float* x, int x_ld, void* y3, int y_ld, long plane, int kmajor, const float* g, const float* b, float eps,
+                        long rows, int D, void* stream);
+int pf_vit_attention_qkv_split3(const void* qkv, void* out3, long plane, int kmajor, int B, int S, int Hh, void* stream);
 /* The same attention entirely in split precision: qkv3 = the QKV GEMM's output as three bf16 planes [3][B*S][3*Hh*64] (plane stride plane_in
  * elements), out3 = three bf16 planes [3][B*S][Hh*64] (plane_out); S^T = K.Q^T and O^T = V^T.P^T as six bf16 partial products each with float32
  * accumulation, float32 softmax with the probabilities split in registers (csrc/vit.hip vit_attention_split3_kernel; attention.py:53-60). */
-int pf_vit_attention_split3(const void* qkv3, long plane_in, void* out3, long plane_out, int B, int S, int Hh, void* stream);
+int pf_vit_attention_split3(const void* qkv3, long plane_in, void* out3, long plane_out, int kmajor, int B, int S, int Hh, void* stream);
 /* float32 [rows][x_ld] -> three bf16 planes [3][rows][y_ld], plane stride `plane` elements (the split producers fuse into their stores) */
 int pf_split3(const float* x, int x_ld, void* y, int y_ld, long plane, long rows, int cols, void* stream);
 

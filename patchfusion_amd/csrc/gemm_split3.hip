@@ -306,7 +306,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split3_kernel(const pf_conv
         v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
       }
       if (p.out_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + y_base + (long)m * p.y_ld + n) = make_float4(v[0], v[1], v[2], v[3]);
-      else store_split3(reinterpret_cast<bf16_t*>(p.y) + (long)m * p.y_ld + n, p.y_bstride, v);
+      else store_split3(reinterpret_cast<bf16_t*>(p.y) + split3_at(m, n, p.y_ld, (p.korder & 8) ? M : 0), p.y_bstride, v);
       }
     }
   }
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(512) void gemm_split3_persist_kernel(const pf_conv_
               v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
             }
             if (p.out_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + y_base + (long)m * p.y_ld + n) = make_float4(v[0], v[1], v[2], v[3]);
-            else store_split3(reinterpret_cast<bf16_t*>(p.y) + (long)m * p.y_ld + n, p.y_bstride, v);
+            else store_split3(reinterpret_cast<bf16_t*>(p.y) + split3_at(m, n, p.y_ld, (p.korder & 8) ? M : 0), p.y_bstride, v);
           }
         }
         acc[fn][fm] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -664,7 +664,8 @@ extern "C" int pf_gemm_split3(const pf_conv_params* p, void* stream) {
   else if ((p->res && p->res_ld % 4) || (p->res2 && p->res2_ld % 4)) e = "residual ld must be a multiple of 4";
   else if ((long)p->B * p->OH * p->OW <= 0 || (long)p->B * p->OH * p->OW >= (1L << 31)) e = "bad token count";
   else if (p->x_bstride <= 0 || p->w_bstride <= 0 || (!p->out_f32 && p->y_bstride <= 0)) e = "plane strides missing";
-  else if (((p->korder & 2) && p->x_ld != p->Cin) || ((p->korder & 4) && p->Kpad != p->Cin) || (p->korder & ~6)) e = "chunk-major operands are dense: x_ld == Kpad == Cin";
+  else if (((p->korder & 2) && p->x_ld != p->Cin) || ((p->korder & 4) && p->Kpad != p->Cin) || (p->korder & ~14)) e = "chunk-major operands are dense: x_ld == Kpad == Cin";
+  else if ((p->korder & 8) && (p->out_f32 || p->y_ld != p->Cout || p->Cout % 32)) e = "chunk-major output: three planes, y_ld == Cout, Cout % 32 == 0";
   else if ((long)p->B * p->OH * p->OW * 64 >= (1L << 31) || (long)p->w_rows * 64 >= (1L << 31)) e = "too many rows for a chunk-major slab";
 #ifdef PF_S3_DBG
   else if (p->batch > 1 && (!p->out_f32 || p->bias || p->scale || p->res || p->batch > 65535)) e = "batched planes: float32 output, no epilogue";
@@ -698,6 +699,7 @@ extern "C" int pf_gemm_bf16_pp(const pf_conv_params* p, void* stream) {
   if (p->Cout <= 0 || p->Cout % 4 || p->y_ld % 4 || p->w_rows < p->Cout || (p->res && p->res_ld % 4) || (p->res2 && p->res2_ld % 4)) return PF_ERR_ARG;
   if ((long)p->B * p->OH * p->OW <= 0 || (long)p->B * p->OH * p->OW >= (1L << 31)) return PF_ERR_ARG;
   pf_conv_params pd = *p;
+  pd.korder = 0;
   pd.x_bstride = 32;                     // "planes" = consecutive 32-deep K sub-chunks of the one bf16 matrix
   pd.w_bstride = 32;
   return launch<256, 128, 4, 2, 3, true, 2, true>(pd, reinterpret_cast<hipStream_t>(stream));

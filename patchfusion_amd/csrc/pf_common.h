@@ -95,6 +95,12 @@ __device__ __forceinline__ void store_split3(bf16_t* y, long plane, const float 
   *reinterpret_cast<uint2*>(y + 2 * plane) = make_uint2(l0, l1);
 }
 
+// element offset of (row, col) in one plane of a split-precision operand: row-major [rows][ld] (kmaj_rows == 0) or CHUNK-MAJOR
+// [cols/32][kmaj_rows][32] (csrc/gemm_split3.hip: every 32-deep K chunk of all rows is one contiguous slab); col % 4 == 0 runs stay inside a chunk
+__device__ __forceinline__ long split3_at(long row, int col, int ld, long kmaj_rows) {
+  return kmaj_rows ? ((long)(col >> 5) * kmaj_rows + row) * 32 + (col & 31) : row * ld + col;
+}
+
 __device__ __forceinline__ void load4(const float* p, float (&v)[4]) {
   float4 a = *reinterpret_cast<const float4*>(p);
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;

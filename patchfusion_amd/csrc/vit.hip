@@ -94,8 +94,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 }
 
 // LayerNorm of float32 rows with the output as three bf16 planes (x = h + m + l) for the split-precision GEMM (csrc/gemm_split3.hip)
+// kmaj_rows != 0: the planes are chunk-major [D/32][kmaj_rows][32] (pf_common.h split3_at)
 __global__ __launch_bounds__(256) void layernorm_split3_kernel(const float* __restrict__ x, int x_ld, bf16_t* __restrict__ y, int y_ld, long plane,
-                                                               const float* __restrict__ g, const float* __restrict__ bta, float eps, long rows, int D) {
+                                                               const float* __restrict__ g, const float* __restrict__ bta, float eps, long rows, int D,
+                                                               long kmaj_rows) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -132,8 +134,9 @@ __global__ __launch_bounds__(256) void layernorm_split3_kernel(const float* __re
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * g[vi * 8 + e] + bta[vi * 8 + e];
       const float lo[4] = {o[0], o[1], o[2], o[3]}, hi[4] = {o[4], o[5], o[6], o[7]};
-      store_split3(yr + vi * 8, plane, lo);
-      store_split3(yr + vi * 8 + 4, plane, hi);
+      bf16_t* yo = kmaj_rows ? y + split3_at(row, vi * 8, y_ld, kmaj_rows) : yr + vi * 8;
+      store_split3(yo, plane, lo);
+      store_split3(yo + 4, plane, hi);
     }
   }
 }
@@ -546,7 +549,7 @@ __global__ __launch_bounds__(256) void vit_attention32_kernel(const bf16_t* __re
 // ---------------------------------------------------------------------------------------------
 template <int QG>      // query groups of 16 per wave: a block covers 64 QG queries; the K / V^T fragments are read once for all groups
 __global__ __launch_bounds__(256, QG == 1 ? 3 : 2) void vit_attention_qkv_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, int B, int S,
-                                                                     int Hh, float qscale, long plane) {
+                                                                     int Hh, float qscale, long plane, long kmaj_rows) {
   constexpr int ROWB = 256;
   __shared__ __attribute__((aligned(16))) char lds[2 * 64 * ROWB];
   char* Ks = lds;                       // [key][d]  16-byte slot ^ (key & 15)
@@ -712,7 +715,7 @@ __global__ __launch_bounds__(256, QG == 1 ? 3 : 2) void vit_attention_qkv_f32_ke
 #pragma unroll
         for (int fd = 0; fd < 4; ++fd) {
           const float w4[4] = {o[qg][fd][0] * inv, o[qg][fd][1] * inv, o[qg][fd][2] * inv, o[qg][fd][3] * inv};
-          store_split3(reinterpret_cast<bf16_t*>(out) + at + fd * 16, plane, w4);
+          store_split3(reinterpret_cast<bf16_t*>(out) + split3_at((long)b * S + qo, h * 64 + g * 4 + fd * 16, D, kmaj_rows), plane, w4);
         }
       } else {
         float* dst = out + at;
@@ -738,7 +741,7 @@ __global__ __launch_bounds__(256, QG == 1 ? 3 : 2) void vit_attention_qkv_f32_ke
 // holds keys 16 kf + 4 g + e.  O^T fragment df (16 d): A = V^T rows (lane (r = d, g): the eight permuted keys of block kk), B = P.
 // ---------------------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 3) void vit_attention_split3_kernel(const bf16_t* __restrict__ qkv3, long plane_in, bf16_t* __restrict__ out3,
-                                                                      long plane_out, int B, int S, int Hh, float qscale) {
+                                                                      long plane_out, int B, int S, int Hh, float qscale, long kmaj_rows) {
   __shared__ __attribute__((aligned(16))) char lds[2 * 3 * 64 * 128];
   char* Ks = lds;
   char* Vs = lds + 3 * 64 * 128;
@@ -923,7 +926,7 @@ __global__ __launch_bounds__(256, 3) void vit_attention_split3_kernel(const bf16
 #pragma unroll
     for (int fd = 0; fd < 4; ++fd) {
       const float w4[4] = {o[fd][0] * inv, o[fd][1] * inv, o[fd][2] * inv, o[fd][3] * inv};
-      store_split3(out3 + at + fd * 16, plane_out, w4);
+      store_split3(out3 + (kmaj_rows ? split3_at((long)b * S + qo, h * 64 + g * 4 + fd * 16, D, kmaj_rows) : at + fd * 16), plane_out, w4);
     }
   }
 }
@@ -987,7 +990,7 @@ extern "C" int pf_vit_attention(const void* q, const void* k, const void* vt, vo
   return ok();
 }
 
-static int attention_qkv(const void* qkv, void* out, long plane, int B, int S, int Hh, void* stream) {
+static int attention_qkv(const void* qkv, void* out, long plane, int B, int S, int Hh, void* stream, long kmaj_rows = 0) {
   // head_dim^-1/2 (attention.py:55, 64^-1/2) times log2(e): the kernel's softmax runs on base-2 logits
   const float qscale = 0.125f * 1.4426950408889634f;
   // 16 queries per wave, three blocks per CU (default).  PF_ATTN_QG=2: 32 queries per wave -- the K / V^T fragments and the staging of a
@@ -995,8 +998,8 @@ static int attention_qkv(const void* qkv, void* out, long plane, int B, int S, i
   // for A/B measurements only
   static int qg = -1;
   if (qg < 0) { const char* e = getenv("PF_ATTN_QG"); qg = (e && e[0] == '2') ? 2 : 1; }
-  if (qg == 2) hipLaunchKernelGGL(vit_attention_qkv_f32_kernel<2>, dim3((S + 127) / 128, B * Hh), dim3(256), 0, ST(stream), (const float*)qkv, (float*)out, B, S, Hh, qscale, plane);
-  else hipLaunchKernelGGL(vit_attention_qkv_f32_kernel<1>, dim3((S + 63) / 64, B * Hh), dim3(256), 0, ST(stream), (const float*)qkv, (float*)out, B, S, Hh, qscale, plane);
+  if (qg == 2) hipLaunchKernelGGL(vit_attention_qkv_f32_kernel<2>, dim3((S + 127) / 128, B * Hh), dim3(256), 0, ST(stream), (const float*)qkv, (float*)out, B, S, Hh, qscale, plane, kmaj_rows);
+  else hipLaunchKernelGGL(vit_attention_qkv_f32_kernel<1>, dim3((S + 63) / 64, B * Hh), dim3(256), 0, ST(stream), (const float*)qkv, (float*)out, B, S, Hh, qscale, plane, kmaj_rows);
   return ok();
 }
 
@@ -1005,22 +1008,24 @@ extern "C" int pf_vit_attention_qkv(const void* qkv, void* out, int B, int S, in
   return attention_qkv(qkv, out, 0, B, S, Hh, stream);
 }
 
-extern "C" int pf_vit_attention_qkv_split3(const void* qkv, void* out3, long plane, int B, int S, int Hh, void* stream) {
+extern "C" int pf_vit_attention_qkv_split3(const void* qkv, void* out3, long plane, int kmajor, int B, int S, int Hh, void* stream) {
   if (!qkv || !out3 || B <= 0 || S <= 0 || Hh <= 0 || plane < (long)B * S * Hh * 64) return PF_ERR_ARG;
-  return attention_qkv(qkv, out3, plane, B, S, Hh, stream);
+  return attention_qkv(qkv, out3, plane, B, S, Hh, stream, kmajor ? (long)B * S : 0);
 }
 
-extern "C" int pf_layernorm_split3(const float* x, int x_ld, void* y3, int y_ld, long plane, const float* g, const float* b, float eps,
+extern "C" int pf_layernorm_split3(const float* x, int x_ld, void* y3, int y_ld, long plane, int kmajor, const float* g, const float* b, float eps,
                                    long rows, int D, void* stream) {
   if (!x || !y3 || !g || !b || D % 8 || D > 2048 || x_ld % 8 || y_ld % 8 || rows <= 0 || plane < (rows - 1) * y_ld + D) return PF_ERR_ARG;
-  hipLaunchKernelGGL(layernorm_split3_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST(stream), x, x_ld, (bf16_t*)y3, y_ld, plane, g, b, eps, rows, D);
+  if (kmajor && (D % 32 || y_ld != D)) return PF_ERR_ARG;                        // chunk-major planes are dense: [D/32][rows][32]
+  hipLaunchKernelGGL(layernorm_split3_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST(stream), x, x_ld, (bf16_t*)y3, y_ld, plane, g, b, eps, rows, D,
+                     kmajor ? rows : 0L);
   return ok();
 }
 
-extern "C" int pf_vit_attention_split3(const void* qkv3, long plane_in, void* out3, long plane_out, int B, int S, int Hh, void* stream) {
+extern "C" int pf_vit_attention_split3(const void* qkv3, long plane_in, void* out3, long plane_out, int kmajor, int B, int S, int Hh, void* stream) {
   if (!qkv3 || !out3 || B <= 0 || S <= 0 || Hh <= 0 || plane_in < (long)B * S * Hh * 192 || plane_out < (long)B * S * Hh * 64) return PF_ERR_ARG;
   const float qscale = 0.125f * 1.4426950408889634f;        // head_dim^-1/2 (attention.py:55) times log2(e): base-2 softmax
   hipLaunchKernelGGL(vit_attention_split3_kernel, dim3((S + 63) / 64, B * Hh), dim3(256), 0, ST(stream), (const bf16_t*)qkv3, plane_in, (bf16_t*)out3,
-                     plane_out, B, S, Hh, qscale);
+                     plane_out, B, S, Hh, qscale, kmajor ? (long)B * S : 0L);
   return ok();
 }

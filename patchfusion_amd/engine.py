@@ -256,14 +256,18 @@ class BranchNet:
         if taps is not None:
             taps["vit_tokens_in"] = tok.clone()
         feats = []
-        hbuf = ops.empty((B * S, D), dt, dev)
-        qkv = ops.empty((B * S, 3 * D), dt, dev)
-        att = ops.empty((B * S, D), dt, dev)
-        mid = ops.empty((B * S, 4 * D), dt, dev)
-        if self.split3:                                            # operands of the split GEMMs travel as three bf16 planes
-            hbuf, att, mid = (ops.empty((3, B * S, n), torch.bfloat16, dev) for n in (D, D, 4 * D))
-            if attention_split3_enabled():                         # ... and so do q / k / v: attention in split precision (csrc/vit.hip)
-                qkv = ops.empty((3, B * S, 3 * D), torch.bfloat16, dev)
+        if self.split3:                                            # operands of the split GEMMs travel as three bf16 planes ...
+            if pk.split3_kmajor_enabled():                         # ... chunk-major [3, K/32, rows, 32]: whole-cache-line DMA pieces (csrc/gemm_split3.hip)
+                hbuf, att, mid = (ops.empty((3, n // 32, B * S, 32), torch.bfloat16, dev) for n in (D, D, 4 * D))
+            else:
+                hbuf, att, mid = (ops.empty((3, B * S, n), torch.bfloat16, dev) for n in (D, D, 4 * D))
+            # ... and so do q / k / v (row-major: the attention kernel reads token rows): attention in split precision (csrc/vit.hip)
+            qkv = ops.empty((3, B * S, 3 * D), torch.bfloat16, dev) if attention_split3_enabled() else ops.empty((B * S, 3 * D), dt, dev)
+        else:
+            hbuf = ops.empty((B * S, D), dt, dev)
+            qkv = ops.empty((B * S, 3 * D), dt, dev)
+            att = ops.empty((B * S, D), dt, dev)
+            mid = ops.empty((B * S, 4 * D), dt, dev)
         for i, blk in enumerate(self.blocks):
             if self.split3:
                 ops.layernorm_split3(x, hbuf, blk["n1"][0], blk["n1"][1], 1e-6)

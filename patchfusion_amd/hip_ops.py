@@ -306,20 +306,38 @@ class HipOps:
     def conv_split3(x3, pw: PackedConv, y, act=None, res=None, res2=None, _timed=None):
         """x3 bfloat16 [3, M, K] planes; pw from packing.pack_conv_split3; y float32 [M, N] or bfloat16 [3, M, N] planes (split output);
         res / res2 float32 [M, N].  float32-grade linear layer on the bf16 matrix cores (csrc/gemm_split3.hip)."""
-        assert x3.dtype == torch.bfloat16 and x3.dim() == 3 and x3.shape[0] == 3 and x3.stride(2) == 1 and pw.w.dtype == torch.bfloat16
-        M = x3.shape[1]
+        assert x3.dtype == torch.bfloat16 and x3.shape[0] == 3 and pw.w.dtype == torch.bfloat16
         split_out = y.dtype == torch.bfloat16
         p = ConvParams()
-        p.x, p.x_ld, p.B, p.H, p.W, p.Cin = x3.data_ptr(), x3.stride(1), 1, 1, M, pw.cin
+        korder = 0
+        if x3.dim() == 4:                                     # chunk-major planes [3, K/32, M, 32]
+            assert x3.is_contiguous() and x3.shape[3] == 32 and x3.shape[1] * 32 == pw.cin
+            M = x3.shape[2]
+            p.x, p.x_ld = x3.data_ptr(), pw.cin
+            korder |= 2
+        else:
+            assert x3.dim() == 3 and x3.stride(2) == 1 and x3.shape[2] >= pw.cin
+            M = x3.shape[1]
+            p.x, p.x_ld = x3.data_ptr(), x3.stride(1)
+        p.B, p.H, p.W, p.Cin = 1, 1, M, pw.cin
         p.x_bstride = x3.stride(0)
-        p.w, p.w_rows, p.Kpad, p.w_bstride = pw.w.data_ptr(), pw.w.shape[1], pw.w.shape[2], pw.w.stride(0)
+        if pw.w.dim() == 4:                                   # chunk-major weight planes [3, K/32, rows, 32] (packing.pack_conv_split3)
+            assert pw.w.is_contiguous() and pw.w.shape[1] * 32 == pw.cin
+            p.w, p.w_rows, p.Kpad, p.w_bstride = pw.w.data_ptr(), pw.w.shape[2], pw.cin, pw.w.stride(0)
+            korder |= 4
+        else:
+            p.w, p.w_rows, p.Kpad, p.w_bstride = pw.w.data_ptr(), pw.w.shape[1], pw.w.shape[2], pw.w.stride(0)
         p.bias = pw.bias.data_ptr() if pw.bias is not None else None
         p.scale = pw.scale.data_ptr() if pw.scale is not None else None
         p.res = res.data_ptr() if res is not None else None
         p.res_ld = res.stride(-2) if res is not None else 0
         p.res2 = res2.data_ptr() if res2 is not None else None
         p.res2_ld = res2.stride(-2) if res2 is not None else 0
-        if split_out:
+        if split_out and y.dim() == 4:                        # chunk-major output planes [3, N/32, M, 32]
+            assert y.is_contiguous() and tuple(y.shape) == (3, pw.cout // 32, M, 32) and pw.cout % 32 == 0
+            p.y, p.y_ld, p.y_bstride, p.out_f32 = y.data_ptr(), pw.cout, y.stride(0), 0
+            korder |= 8
+        elif split_out:
             assert y.dim() == 3 and y.shape[0] == 3 and y.shape[1] == M and y.stride(2) == 1
             p.y, p.y_ld, p.y_bstride, p.out_f32 = y.data_ptr(), y.stride(1), y.stride(0), 0
         else:
@@ -327,12 +345,12 @@ class HipOps:
             p.y, p.y_ld, p.out_f32 = y.data_ptr(), y.stride(-2), 1
         p.OH, p.OW, p.Cout = 1, M, pw.cout
         p.KH = p.KW = p.stride = 1
-        p.act, p.shuffle, p.dtype = ACT[act], 1, 1
+        p.act, p.shuffle, p.dtype, p.korder = ACT[act], 1, 1, korder
         for t in (x3, y, pw.w, res, res2):
             _p(t)                                             # (device / layout checks of every tensor handed to the library)
         for t in (res, res2):
             assert t is None or (t.dtype == torch.float32 and t.shape[-1] >= pw.cout and t.shape[-2] == M), "residuals are float32 [M, >= N]"
-        assert (y.shape[-1] >= pw.cout and y.shape[-2] == M) and x3.shape[2] >= pw.cin
+        assert y.dim() == 4 or (y.shape[-1] >= pw.cout and y.shape[-2] == M)
         if _timed is not None:
             ms = C.c_float(0)
             check(_L.pf_gemm_split3_timed(C.byref(p), int(_timed), C.byref(ms), _stream()), "pf_gemm_split3_timed")
@@ -365,11 +383,17 @@ class HipOps:
 
     @staticmethod
     def layernorm_split3(x, y3, g, b, eps):
-        """LayerNorm of float32 rows x [M, D], output as three bfloat16 planes y3 [3, M, D] (input of ops.conv_split3)"""
-        assert x.dtype == torch.float32 and y3.dtype == torch.bfloat16 and y3.dim() == 3 and y3.shape[0] == 3 and y3.stride(2) == 1
+        """LayerNorm of float32 rows x [M, D], output as three bfloat16 planes (input of ops.conv_split3): y3 [3, M, D] row-major or
+        [3, D/32, M, 32] chunk-major"""
+        assert x.dtype == torch.float32 and y3.dtype == torch.bfloat16 and y3.shape[0] == 3
         M, D = x.shape
-        assert y3.shape[1] == M and y3.shape[2] == D
-        check(_L.pf_layernorm_split3(_p(x), x.stride(0), _p(y3), y3.stride(1), y3.stride(0), _p(g), _p(b), float(eps), M, D, _stream()),
+        if y3.dim() == 4:
+            assert y3.is_contiguous() and tuple(y3.shape) == (3, D // 32, M, 32)
+            check(_L.pf_layernorm_split3(_p(x), x.stride(0), _p(y3), D, y3.stride(0), 1, _p(g), _p(b), float(eps), M, D, _stream()),
+                  "pf_layernorm_split3")
+            return y3
+        assert y3.dim() == 3 and y3.stride(2) == 1 and y3.shape[1] == M and y3.shape[2] == D
+        check(_L.pf_layernorm_split3(_p(x), x.stride(0), _p(y3), y3.stride(1), y3.stride(0), 0, _p(g), _p(b), float(eps), M, D, _stream()),
               "pf_layernorm_split3")
         return y3
 
@@ -377,19 +401,21 @@ class HipOps:
     def vit_attention(qkv, out, B, S, heads):
         """qkv [B*S, 3*D] -> out [B*S, D]; head_dim must be 64.  float32 qkv with a bfloat16 out [3, B*S, D]: the output is written as
         the three split planes of the projection GEMM (ops.conv_split3)."""
+        kmaj = int(out.dim() == 4)                            # output planes chunk-major [3, D/32, B*S, 32] (input of the projection GEMM)
         if qkv.dim() == 3:
             # the QKV GEMM's output as three bf16 planes [3, B*S, 3*D]: attention entirely in split precision (csrc/vit.hip)
             D = qkv.shape[2] // 3
-            assert qkv.dtype == out.dtype == torch.bfloat16 and tuple(qkv.shape) == (3, B * S, 3 * D) and tuple(out.shape) == (3, B * S, D)
+            assert qkv.dtype == out.dtype == torch.bfloat16 and tuple(qkv.shape) == (3, B * S, 3 * D)
+            assert tuple(out.shape) == ((3, D // 32, B * S, 32) if kmaj else (3, B * S, D))
             assert D == heads * 64 and qkv.is_contiguous() and out.is_contiguous()
-            check(_L.pf_vit_attention_split3(_p(qkv), qkv.stride(0), _p(out), out.stride(0), B, S, heads, _stream()), "pf_vit_attention_split3")
+            check(_L.pf_vit_attention_split3(_p(qkv), qkv.stride(0), _p(out), out.stride(0), kmaj, B, S, heads, _stream()), "pf_vit_attention_split3")
             return
         D = qkv.shape[1] // 3
         assert D == heads * 64 and qkv.is_contiguous() and out.is_contiguous()
         import os
         if qkv.dtype == torch.float32 and out.dtype == torch.bfloat16:
-            assert tuple(out.shape) == (3, B * S, D)
-            check(_L.pf_vit_attention_qkv_split3(_p(qkv), _p(out), out.stride(0), B, S, heads, _stream()), "pf_vit_attention_qkv_split3")
+            assert tuple(out.shape) == ((3, D // 32, B * S, 32) if kmaj else (3, B * S, D))
+            check(_L.pf_vit_attention_qkv_split3(_p(qkv), _p(out), out.stride(0), kmaj, B, S, heads, _stream()), "pf_vit_attention_qkv_split3")
             return
         if qkv.dtype == torch.float32 and os.environ.get("PF_ATTN_QKV", "1") != "0":
             # f32: the attention kernel reads q / k / v rows straight out of the QKV GEMM's output (csrc/vit.hip, version 2)

@@ -212,9 +212,31 @@ def split3(x):
     return h, m, l
 
 
-def pack_conv_split3(weight, bias=None, *, scale=None):
+def split3_kmajor_enabled():
+    """operands of the split-precision linears in the chunk-major layout [K/32][rows][32]?  PF_SPLIT3_KMAJOR=0 / 1, default on"""
+    import os
+    return os.environ.get("PF_SPLIT3_KMAJOR", "1") != "0"
+
+
+def rows_to_kmajor(t):
+    """[..., rows, K] -> chunk-major [..., K/32, rows, 32] (contiguous)"""
+    *lead, rows, K = t.shape
+    assert K % 32 == 0
+    n = len(lead)
+    return t.reshape(*lead, rows, K // 32, 32).permute(*range(n), n + 1, n, n + 2).contiguous()
+
+
+def kmajor_to_rows(t):
+    """chunk-major [..., K/32, rows, 32] -> [..., rows, K]"""
+    *lead, nk, rows, c = t.shape
+    n = len(lead)
+    return t.permute(*range(n), n + 1, n, n + 2).reshape(*lead, rows, nk * c)
+
+
+def pack_conv_split3(weight, bias=None, *, scale=None, kmajor=None):
     """nn.Linear / 1x1 conv weight [Cout, Cin] for the split-precision GEMM (csrc/gemm_split3.hip): PackedConv with w = [3, rows, Kpad]
-    bfloat16 planes (h, m, l), K padded to 32, rows to 16; bias / scale float32 as in pack_conv."""
+    bfloat16 planes (h, m, l), K padded to 32, rows to 16; bias / scale float32 as in pack_conv.  kmajor (default: split3_kmajor_enabled()):
+    the planes are CHUNK-MAJOR, w = [3, Kpad/32, rows, 32] -- every 32-deep K chunk of all rows is one contiguous slab (csrc/gemm_split3.hip)."""
     w = weight.detach().float().cpu()
     if w.dim() == 4:
         assert w.shape[2] == 1 and w.shape[3] == 1
@@ -226,6 +248,8 @@ def pack_conv_split3(weight, bias=None, *, scale=None):
     wp = torch.zeros(rows, cin)
     wp[:cout] = w
     planes = torch.stack(split3(wp)).contiguous()
+    if split3_kmajor_enabled() if kmajor is None else kmajor:
+        planes = rows_to_kmajor(planes)
     bp = None
     if bias is not None:
         bp = torch.zeros(rows)

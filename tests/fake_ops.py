@@ -12,7 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import third_party as tp
-from patchfusion_amd.packing import split3 as pk_split3, unpack_conv, winograd_applies
+from patchfusion_amd.packing import kmajor_to_rows, rows_to_kmajor, split3 as pk_split3, unpack_conv, winograd_applies
 
 
 def _as4(t):
@@ -132,7 +132,15 @@ class FakeOps:
     @staticmethod
     def _store3(y3, v):
         h, m, l = pk_split3(v)
-        y3[0], y3[1], y3[2] = h, m, l
+        if y3.dim() == 4:                                    # chunk-major planes [3, cols/32, rows, 32] (packing.rows_to_kmajor)
+            y3[:] = rows_to_kmajor(torch.stack([h, m, l]))
+        else:
+            y3[0], y3[1], y3[2] = h, m, l
+
+    @staticmethod
+    def _rows(t3):
+        """three planes, row-major [3, rows, cols] or chunk-major [3, cols/32, rows, 32] -> float32 [rows, cols] (exact sum)"""
+        return (kmajor_to_rows(t3) if t3.dim() == 4 else t3).float().sum(0)
 
     @staticmethod
     def split3(x, y3):
@@ -141,8 +149,8 @@ class FakeOps:
 
     @staticmethod
     def conv_split3(x3, pw, y, act=None, res=None, res2=None):
-        x = x3.float().sum(0)
-        w = pw.w.float().sum(0)[:pw.cout, :pw.cin].to(x.device)
+        x = FakeOps._rows(x3)
+        w = FakeOps._rows(pw.w)[:pw.cout, :pw.cin].to(x.device)
         v = x[:, :pw.cin] @ w.t()
         if pw.bias is not None:
             v = v + pw.bias[:pw.cout].to(v.device)
@@ -154,7 +162,7 @@ class FakeOps:
         if res2 is not None:
             v = v + res2[:, :pw.cout].float()
         if y.dtype == torch.bfloat16:
-            FakeOps._store3(y[:, :, :pw.cout], v)
+            FakeOps._store3(y if y.dim() == 4 else y[:, :, :pw.cout], v)
         else:
             y[:, :pw.cout] = v
         return y

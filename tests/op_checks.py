@@ -504,6 +504,38 @@ def gemm_split3(dt):
     info.append(f"layernorm planes identical={ln_same} attention planes identical={at_same}")
     if not (ln_same and at_same):
         return float("inf"), 2e-6, "; ".join(info)
+    # CHUNK-MAJOR planes ([3, cols/32, rows, 32]: the layout the ViT blocks hand from producer to GEMM): every producer writes the same bits as
+    # its row-major form, and a GEMM fed / storing chunk-major planes returns the same bits, through the one-tile and the persistent kernel
+    M2 = 2 * 1037
+    y3k = torch.zeros(3, 32, M2, 32, dtype=torch.bfloat16, device=DEV)
+    o.layernorm_split3(xs, y3k, gam, bet, 1e-6)
+    k_ln = bool((pk.kmajor_to_rows(y3k) == y3).all())
+    a3k = torch.zeros(3, 32, M2, 32, dtype=torch.bfloat16, device=DEV)
+    o.vit_attention(qkv, a3k, 2, 1037, 16)
+    k_at = bool((pk.kmajor_to_rows(a3k) == a3).all())
+    q3 = torch.stack(pk.split3(qkv.cpu())).contiguous().to(DEV)
+    s3, s3k = torch.zeros_like(a3), torch.zeros_like(a3k)
+    o.vit_attention(q3, s3, 2, 1037, 16)
+    o.vit_attention(q3, s3k, 2, 1037, 16)
+    k_as = bool((pk.kmajor_to_rows(s3k) == s3).all())
+    w = torch.randn(4096, 1024, generator=g) / 32
+    b = torch.randn(4096, generator=g)
+    pr, pc = pk.pack_conv_split3(w, b, kmajor=False).to(DEV), pk.pack_conv_split3(w, b, kmajor=True).to(DEV)
+    k_gemm = True
+    for pers in ("0", "2"):
+        os.environ["PF_S3_PERSIST"], os.environ["PF_S3_GRID"] = pers, "40"
+        yr = torch.zeros(3, M2, 4096, dtype=torch.bfloat16, device=DEV)
+        o.conv_split3(y3, pr, yr, act="gelu")
+        yk = torch.zeros(3, 128, M2, 32, dtype=torch.bfloat16, device=DEV)
+        o.conv_split3(y3k, pc, yk, act="gelu")
+        ym = torch.zeros(3, M2, 4096, dtype=torch.bfloat16, device=DEV)
+        o.conv_split3(y3k, pr, ym, act="gelu")                      # mixed: chunk-major x, row-major w and y
+        k_gemm = k_gemm and bool((pk.kmajor_to_rows(yk) == yr).all()) and bool((ym == yr).all())
+    for k in ("PF_S3_PERSIST", "PF_S3_GRID"):
+        os.environ.pop(k, None)
+    info.append(f"chunk-major: layernorm={k_ln} attention(f32 qkv)={k_at} attention(split)={k_as} gemm in/out={k_gemm}")
+    if not (k_ln and k_at and k_as and k_gemm):
+        return float("inf"), 2e-6, "; ".join(info)
     return max(errs), 2e-6, "; ".join(info)
 
 

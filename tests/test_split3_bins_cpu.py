@@ -25,9 +25,14 @@ def test_pack_conv_split3_layout_and_six_term_product():
     g = torch.Generator().manual_seed(1)
     w = torch.randn(10, 64, generator=g)
     b = torch.randn(10, generator=g)
-    pw = pk.pack_conv_split3(w, b, scale=torch.rand(10, generator=g))
+    sc = torch.rand(10, generator=g)
+    pw = pk.pack_conv_split3(w, b, scale=sc, kmajor=False)
     assert tuple(pw.w.shape) == (3, 16, 64) and pw.cout == 12 and pw.cout_real == 10 and pw.cin == 64
     assert bool((pw.w.double().sum(0)[:10] == w.double()).all()) and float(pw.w.float()[:, 10:].abs().max()) == 0.0
+    # chunk-major planes (the default): [3, K/32, rows, 32], the same bits -- every 32-deep K chunk of all rows is one slab
+    pk_ = pk.pack_conv_split3(w, b, scale=sc, kmajor=True)
+    assert tuple(pk_.w.shape) == (3, 2, 16, 32) and pk_.w.is_contiguous() and bool((pk.kmajor_to_rows(pk_.w) == pw.w).all())
+    assert bool((pk_.w[:, 1, 3] == pw.w[:, 3, 32:]).all()) and bool((pk.rows_to_kmajor(pw.w) == pk_.w).all())
     # the six products the kernel evaluates, in float64: error O(2^-24) of sum |x||w|, the three dropped terms
     x = torch.randn(33, 64, generator=g)
     xs, ws = torch.stack(pk.split3(x)).double(), pw.w.double()[:, :10]

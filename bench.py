@@ -278,8 +278,10 @@ def roofline(dtype, dev, gemm_only=False):
     profiles/r3_pmc_dominant_<dtype>.json was measured on EXACTLY this kernel source (sha of igemm.hip + wino_fused.hip + pf_common.h); otherwise null.
     NOTE on its meaning: FETCH_SIZE / WRITE_SIZE count the L2's fabric-side requests; reads served by the 256 MiB Infinity Cache are included, so
     for the fused Winograd kernel (whose 43 MB filter set and 10 MB halo groups are re-streamed through L2 by design) it is an UPPER bound on HBM bytes."""
+    from patchfusion_amd import hip_ops
     from patchfusion_amd import packing as pk
     from patchfusion_amd.hip_ops import ops
+    hip_ops.refresh_env()             # (the PF_* switches are cached per engine build; this function runs outside one)
     tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
     B, H, W, C = 8, 392, 518, 544
     w = torch.randn(C, C, 3, 3) / (9 * C) ** 0.5
@@ -294,7 +296,6 @@ def roofline(dtype, dev, gemm_only=False):
     except Exception:
         pass
     direct_flops = 2.0 * B * H * W * 9 * C * C
-    from patchfusion_amd import hip_ops
     if (pw.wino_u3 is not None and pk.winograd_applies(pw, B * H * W, 1, 1, "relu") and hip_ops._split3_three_step(pw) and
             not hip_ops._fused_wanted(B, H, W, pw)):
         # round 3 (late): the layer runs as input transform (three bf16 planes) -> ONE batched split-precision GEMM launch over the 36 transform

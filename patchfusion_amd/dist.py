@@ -13,17 +13,33 @@ import torch.distributed as dist
 from .tiling import shard_range
 
 
+_GATHER_BUF = {}
+
+
 def all_gather_shards(preds, n, world):
-    """preds [n,h,w]: this rank has filled rows shard_range(n, rank, world); returns the full tensor."""
+    """preds [n,h,w]: this rank has filled rows shard_range(n, rank, world); returns the full tensor (every rank: the same bits).
+
+    ONE collective on a preallocated buffer.  Equal shards (n % world == 0: BASELINE configs[3] -- 64 tiles over 8 GPUs -- and every
+    `bench.py --gpus N` split): `all_gather_into_tensor` writes rank r's chunk at rows [r q, (r+1) q) of the result, which IS the tile order --
+    no staging copy on either side (round 3 made a padded send copy, a Python list of `world` receive tensors and `world` scatter copies).
+    Ragged shards: the chunks are padded to the largest one in a cached [world, q, h, w] buffer and compacted with one indexed copy."""
     rank = dist.get_rank()
-    q = (n + world - 1) // world                     # padded equal-size chunks for all_gather_into_tensor
     lo, hi = shard_range(n, rank, world)
-    send = torch.zeros((q,) + tuple(preds.shape[1:]), dtype=preds.dtype, device=preds.device)
+    q, r = divmod(n, world)
+    if r == 0:
+        out = torch.empty_like(preds)
+        dist.all_gather_into_tensor(out, preds[lo:hi].contiguous())       # RCCL (backend 'nccl') on GPUs, gloo in CPU tests
+        return out
+    qp = q + 1
+    key = (world, qp, tuple(preds.shape[1:]), preds.dtype, preds.device)
+    buf = _GATHER_BUF.get(key)
+    if buf is None:
+        if len(_GATHER_BUF) > 4:
+            _GATHER_BUF.clear()
+        rows = torch.cat([torch.arange(l, h) + (rr * qp - l) for rr in range(world) for l, h in [shard_range(n, rr, world)]])
+        buf = _GATHER_BUF[key] = (torch.zeros((world * qp,) + tuple(preds.shape[1:]), dtype=preds.dtype, device=preds.device),
+                                  torch.zeros((qp,) + tuple(preds.shape[1:]), dtype=preds.dtype, device=preds.device), rows.to(preds.device))
+    recv, send, rows = buf
     send[:hi - lo] = preds[lo:hi]
-    recv = [torch.empty_like(send) for _ in range(world)]
-    dist.all_gather(recv, send)                      # RCCL (backend 'nccl') on GPUs, gloo in CPU tests
-    out = torch.empty_like(preds)
-    for r in range(world):
-        l, h = shard_range(n, r, world)
-        out[l:h] = recv[r][:h - l]
-    return out
+    dist.all_gather_into_tensor(recv, send)
+    return recv.index_select(0, rows)

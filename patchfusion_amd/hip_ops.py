@@ -68,19 +68,39 @@ def _ld(t):
     return ld
 
 
+_ENV = {}
+
+
+def _env(name, default):
+    """PF_* switch, resolved ONCE (first use after import / refresh_env) instead of on every library call: round 3 read 4-6 environment
+    variables per convolution, ~20 % of the 22 us the Python host spent per call (tools/host_overhead.py)."""
+    v = _ENV.get(name)
+    if v is None:
+        import os
+        v = _ENV[name] = os.environ.get(name, default)
+    return v
+
+
+def refresh_env():
+    """forget every cached PF_* switch and every cached dispatch decision (called by the engine build and by tests that flip switches)"""
+    _ENV.clear()
+    _CONV_CACHE.clear()
+
+
+_CONV_CACHE = {}
+
+
 def _bf16_pp_enabled():
     """plain bf16 linears through the split GEMM's ping-pong pipeline (pf_gemm_bf16_pp, 256 x 128 tiles): measured and NOT kept -- 0.095 /
     0.047 / 0.118 / 0.126 ms on the ViT-L qkv / proj / fc1 / fc2 shapes against 0.086 / 0.038 / 0.108 / 0.105 for the implicit-GEMM kernels
     (profiles/r3_bf16_pp_sweep.log): one product per fragment pair does not amortise the pipeline the way the split GEMM's six do.
     PF_BF16_PP=1 turns it on (A/B, tests/op_checks.py conv_bf16_pp)."""
-    import os
-    return os.environ.get("PF_BF16_PP", "0") == "1"
+    return _env("PF_BF16_PP", "0") == "1"
 
 
 def _split3_three_step(pw):
     """does the three-step form of this layer run its GEMM in split precision? (filters packed as three planes and PF_WINO_SPLIT3 != 0)"""
-    import os
-    return pw.wino_u3 is not None and os.environ.get("PF_WINO_SPLIT3", "1") != "0"
+    return pw.wino_u3 is not None and _env("PF_WINO_SPLIT3", "1") != "0"
 
 
 def _fused_wanted(B, H, W, pw):
@@ -90,8 +110,7 @@ def _fused_wanted(B, H, W, pw):
     the ceil(Cout/64) channel blocks repeats the input transform, while the batched GEMM of the three-step form runs near its peak there:
     with the split-precision GEMM from 512 output channels on (544->544 @ 8x392x518: 20.7 vs 22.5 ms; 768->768 @ 8x224x296: 10.3 vs 13.5),
     with the f32 GEMM only at 768+ -> 768+ (13.0 vs 13.5).  Below that the fused kernel wins 1.1x (768->256) ... 2.4x (-> 32 channels)."""
-    import os
-    mode = os.environ.get("PF_WINO_FUSED", "1")
+    mode = _env("PF_WINO_FUSED", "1")
     if mode == "0":
         return False
     if mode == "2":
@@ -112,24 +131,36 @@ _WS = {}
 
 def _workspace(device, nV, nM):
     """V / M workspaces of the three-step Winograd path, one growing pair per (device, stream): launches of one stream are ordered, so
-    the pair can be reused by every layer of that stream instead of 2 x 8 GB of fresh allocations per call (round-2 advisor finding)."""
+    the pair can be reused by every layer of that stream instead of 2 x 8 GB of fresh allocations per call (round-2 advisor finding).
+    Growth drops the old buffer BEFORE allocating the larger one (round-3 advisor finding: `v = None` only cleared the local name, the dict
+    still held the old buffer, so old and new coexisted); release_workspaces() frees everything (model teardown / `_apply`)."""
     key = (device.index, torch.cuda.current_stream().cuda_stream)
     v, m = _WS.get(key, (None, None))
-    if v is None or v.numel() < nV:
-        v = None
-        v = torch.empty(nV, dtype=torch.float32, device=device)
-    if m is None or m.numel() < nM:
-        m = None
-        m = torch.empty(nM, dtype=torch.float32, device=device)
-    _WS[key] = (v, m)
+    if v is None or v.numel() < nV or m is None or m.numel() < nM:
+        _WS.pop(key, None)
+        if v is None or v.numel() < nV:
+            v = None
+            v = torch.empty(nV, dtype=torch.float32, device=device)
+        if m is None or m.numel() < nM:
+            m = None
+            m = torch.empty(nM, dtype=torch.float32, device=device)
+        _WS[key] = (v, m)
     return v, m
+
+
+def release_workspaces():
+    """free the per-(device, stream) Winograd arenas (at the headline layer 12 GB + 8 GB per stream); they are re-grown on demand"""
+    _WS.clear()
+
+
+def workspace_bytes():
+    return sum(v.numel() * 4 + m.numel() * 4 for v, m in _WS.values())
 
 
 def _fused_group():
     """PF_WINO_GS: super-tiles per block group (L2 locality knob); PF_WINO_SHAPE: 0 = automatic, 8 | 4 = forced super-tile width (tuning)"""
-    import os
-    return ((int(os.environ.get("PF_WINO_GS", "8")) & 0xffff) | (int(os.environ.get("PF_WINO_SHAPE", "0")) << 16)
-            | (int(os.environ.get("PF_WINO_DBG", "0")) << 20))     # PF_WINO_DBG: timing decomposition only (wrong results), see wino_fused.hip
+    return ((int(_env("PF_WINO_GS", "8")) & 0xffff) | (int(_env("PF_WINO_SHAPE", "0")) << 16)
+            | (int(_env("PF_WINO_DBG", "0")) << 20))     # PF_WINO_DBG: timing decomposition only (wrong results), see wino_fused.hip
 
 
 class HipOps:
@@ -146,7 +177,9 @@ class HipOps:
 
     # ---------------- conv / linear ----------------
     @staticmethod
-    def conv(x, pw: PackedConv, y, stride=1, pad=0, act=None, relu_in=False, res=None, res2=None, _timed=None, _direct=None):
+    def _conv_plan(x, pw, y, stride, pad, act, relu_in, res, res2, direct):
+        """everything about a conv call that does not change while shapes / strides / the packed layer stay the same: the argument checks, the filled
+        pf_conv_params and the dispatch decision ('pp' | 'fused' | 'wino3' | 'wino' | 'direct').  Cached by HipOps.conv per (layer, layout)."""
         x4, y4 = _as4(x), _as4(y)
         B, H, W, _ = x4.shape
         OH = (H + 2 * pad - pw.KH) // stride + 1
@@ -173,75 +206,90 @@ class HipOps:
         p.korder = pw.korder
         for t in (x4, y4, pw.w, res, res2):
             _p(t)
-        if (x4.dtype == torch.bfloat16 and pw.KH == 1 and pw.KW == 1 and stride == 1 and pad == 0 and s == 1 and not relu_in and not _direct and
+        f32_io = y4.dtype == torch.float32 and (res is None or res.dtype == torch.float32) and (res2 is None or res2.dtype == torch.float32)
+        if (x4.dtype == torch.bfloat16 and pw.KH == 1 and pw.KW == 1 and stride == 1 and pad == 0 and s == 1 and not relu_in and not direct and
                 B * H * W >= 2048 and pw.cin % 64 == 0 and pw.cin >= 512 and pw.cout >= 512 and _bf16_pp_enabled()):
             # bf16 linear layers with many token rows (ViT blocks, DPT projections): 256 x 128 ping-pong tiles (csrc/gemm_split3.hip, PLAIN)
-            def run_pp():
-                check(_L.pf_gemm_bf16_pp(C.byref(p), _stream()), "pf_gemm_bf16_pp")
-            if _timed is None:
-                run_pp()
-                return y
-            run_pp()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(int(_timed)):
-                run_pp()
-            e1.record()
-            e1.synchronize()
-            return e0.elapsed_time(e1) / int(_timed)
-        wino = winograd_applies(pw, B * H * W, stride, pad, act) and not _direct
-        if _timed is not None and not wino:
-            ms = C.c_float(0)
-            check(_L.pf_conv_timed(C.byref(p), int(_timed), C.byref(ms), _stream()), "pf_conv_timed")
-            return ms.value
+            return "pp", p, None
+        wino = winograd_applies(pw, B * H * W, stride, pad, act) and not direct
         if wino and pw.wino_up is not None and _fused_wanted(B, H, W, pw) and _L.pf_conv_winograd_fused_supported(C.byref(p)):
             # fused F(4x4,3x3): one kernel, no V / M workspaces (csrc/wino_fused.hip)
-            assert y4.dtype == torch.float32 and (res is None or res.dtype == torch.float32) and (res2 is None or res2.dtype == torch.float32)
-            _p(pw.wino_up)
-            nnb, gs = pw.wino_up.shape[0], _fused_group()
-            if _timed is None:
-                check(_L.pf_conv_winograd_fused(C.byref(p), _p(pw.wino_up), nnb, gs, _stream()), "pf_conv_winograd_fused")
-                return y
-            ms = C.c_float(0)
-            check(_L.pf_conv_winograd_fused_timed(C.byref(p), _p(pw.wino_up), nnb, gs, int(_timed), C.byref(ms), _stream()),
-                  "pf_conv_winograd_fused_timed")
-            return ms.value
-        if wino and pw.wino_u is None:
-            wino = False                                      # fused-only layer below the block threshold: direct kernel
-            if _timed is not None:
-                ms = C.c_float(0)
-                check(_L.pf_conv_timed(C.byref(p), int(_timed), C.byref(ms), _stream()), "pf_conv_timed")
-                return ms.value
-        if wino:
-            # float32 3x3 layers with enough pixels: input transform -> (m+2)^2 GEMMs -> output transform (csrc/winograd.hip)
+            assert f32_io
+            return "fused", p, (_p(pw.wino_up), pw.wino_up.shape[0], _fused_group())
+        if wino and pw.wino_u is not None:
+            # float32 3x3 layers: input transform -> (m+2)^2 GEMMs -> output transform (csrc/winograd.hip)
             m = pw.wino_m
             T = B * -(-H // m) * -(-W // m)
             a2 = (m + 2) ** 2
-            assert y4.dtype == torch.float32 and (res is None or res.dtype == torch.float32) and (res2 is None or res2.dtype == torch.float32)
-            split = m == 4 and _split3_three_step(pw)
-            # (split: V holds three bf16 planes = 6 bytes per element instead of 4)
-            V, Mw = _workspace(x4.device, (a2 * T * pw.cin * 3 + 1) // 2 if split else a2 * T * pw.cin, a2 * T * pw.cout)
+            assert f32_io
+            if m == 4 and _split3_three_step(pw):
+                # (split: V holds three bf16 planes = 6 bytes per element instead of 4; whole tile octets, csrc/winograd.hip)
+                T8 = -(-T // 8) * 8
+                return "wino3", p, (_p(pw.wino_u3), pw.wino_u3.shape[3], pw.wino_u3.shape[2] * 32, (a2 * T8 * pw.cin * 3 + 1) // 2, a2 * T * pw.cout)
+            return "wino", p, (m, _p(pw.wino_u), pw.wino_u.shape[1], pw.wino_u.shape[2], a2 * T * pw.cin, a2 * T * pw.cout)
+        return "direct", p, None          # (incl. fused-only layers below the block threshold)
 
-            def run():
-                if split:
-                    check(_L.pf_conv_winograd_split3(C.byref(p), _p(pw.wino_u3), pw.wino_u3.shape[3], pw.wino_u3.shape[2] * 32, _p(V), _p(Mw), _stream()),
-                          "pf_conv_winograd_split3")
-                    return
-                check(_L.pf_conv_winograd(C.byref(p), m, _p(pw.wino_u), pw.wino_u.shape[1], pw.wino_u.shape[2], _p(V), _p(Mw), _stream()),
-                      "pf_conv_winograd")
-            if _timed is None:
-                run()
-                return y
-            run()                                             # whole three-step layer, events on the launch stream
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(int(_timed)):
-                run()
-            e1.record()
-            e1.synchronize()
-            return e0.elapsed_time(e1) / int(_timed)
-        check(_L.pf_conv(C.byref(p), _stream()), "pf_conv")
-        return y
+    @staticmethod
+    def _conv_exec(route, p, extra, device):
+        if route == "direct":
+            check(_L.pf_conv(C.byref(p), _stream()), "pf_conv")
+        elif route == "fused":
+            check(_L.pf_conv_winograd_fused(C.byref(p), extra[0], extra[1], extra[2], _stream()), "pf_conv_winograd_fused")
+        elif route == "wino3":
+            V, Mw = _workspace(device, extra[3], extra[4])
+            check(_L.pf_conv_winograd_split3(C.byref(p), extra[0], extra[1], extra[2], C.c_void_p(V.data_ptr()), C.c_void_p(Mw.data_ptr()), _stream()),
+                  "pf_conv_winograd_split3")
+        elif route == "wino":
+            V, Mw = _workspace(device, extra[4], extra[5])
+            check(_L.pf_conv_winograd(C.byref(p), extra[0], extra[1], extra[2], extra[3], C.c_void_p(V.data_ptr()), C.c_void_p(Mw.data_ptr()), _stream()),
+                  "pf_conv_winograd")
+        else:
+            check(_L.pf_gemm_bf16_pp(C.byref(p), _stream()), "pf_gemm_bf16_pp")
+
+    @staticmethod
+    def conv(x, pw: PackedConv, y, stride=1, pad=0, act=None, relu_in=False, res=None, res2=None, _timed=None, _direct=None):
+        """y = epi(conv(x)) through the kernel the dispatch rules pick (pf_conv / fused or three-step Winograd / bf16 ping-pong GEMM).
+        The plan of a call -- checks, filled pf_conv_params, route -- is cached per (packed layer, tensor layouts, epilogue); a repeat call only
+        refreshes the four data pointers (round-3 review: 22 us of Python per library call, most of it here)."""
+        if _timed is None and _direct is None:
+            key = (id(pw), x.shape, x.stride(), y.shape, y.stride(), stride, pad, act, relu_in, x.dtype, y.dtype, x.device,
+                   None if res is None else (res.shape, res.stride(), res.dtype), None if res2 is None else (res2.shape, res2.stride(), res2.dtype))
+            ent = _CONV_CACHE.get(key)
+            if ent is None or ent[0] is not pw:
+                if len(_CONV_CACHE) > 4096:
+                    _CONV_CACHE.clear()
+                ent = (pw,) + HipOps._conv_plan(x, pw, y, stride, pad, act, relu_in, res, res2, None)
+                _CONV_CACHE[key] = ent
+            else:
+                p = ent[2]
+                p.x, p.y = x.data_ptr(), y.data_ptr()
+                if res is not None:
+                    p.res = res.data_ptr()
+                if res2 is not None:
+                    p.res2 = res2.data_ptr()
+            HipOps._conv_exec(ent[1], ent[2], ent[3], x.device)
+            return y
+        route, p, extra = HipOps._conv_plan(x, pw, y, stride, pad, act, relu_in, res, res2, _direct)
+        if _timed is None:
+            HipOps._conv_exec(route, p, extra, x.device)
+            return y
+        if route == "direct":
+            ms = C.c_float(0)
+            check(_L.pf_conv_timed(C.byref(p), int(_timed), C.byref(ms), _stream()), "pf_conv_timed")
+            return ms.value
+        if route == "fused":
+            ms = C.c_float(0)
+            check(_L.pf_conv_winograd_fused_timed(C.byref(p), extra[0], extra[1], extra[2], int(_timed), C.byref(ms), _stream()),
+                  "pf_conv_winograd_fused_timed")
+            return ms.value
+        HipOps._conv_exec(route, p, extra, x.device)          # whole three-step layer / ping-pong GEMM: events on the launch stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(int(_timed)):
+            HipOps._conv_exec(route, p, extra, x.device)
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / int(_timed)
 
     @staticmethod
     def gemm_planes_split3(V3, U3, Mw, T, cin, cout, iters=None):
@@ -303,7 +351,7 @@ class HipOps:
         return y3
 
     @staticmethod
-    def conv_split3(x3, pw: PackedConv, y, act=None, res=None, res2=None, _timed=None):
+    def _conv_split3_plan(x3, pw, y, act, res, res2):
         """x3 bfloat16 [3, M, K] planes; pw from packing.pack_conv_split3; y float32 [M, N] or bfloat16 [3, M, N] planes (split output);
         res / res2 float32 [M, N].  float32-grade linear layer on the bf16 matrix cores (csrc/gemm_split3.hip)."""
         assert x3.dtype == torch.bfloat16 and x3.shape[0] == 3 and pw.w.dtype == torch.bfloat16
@@ -351,6 +399,30 @@ class HipOps:
         for t in (res, res2):
             assert t is None or (t.dtype == torch.float32 and t.shape[-1] >= pw.cout and t.shape[-2] == M), "residuals are float32 [M, >= N]"
         assert y.dim() == 4 or (y.shape[-1] >= pw.cout and y.shape[-2] == M)
+        return p
+
+    @staticmethod
+    def conv_split3(x3, pw: PackedConv, y, act=None, res=None, res2=None, _timed=None):
+        """x3 bfloat16 planes, row-major [3, M, K] or chunk-major [3, K/32, M, 32]; pw from packing.pack_conv_split3; y float32 [M, N] or bfloat16
+        planes ([3, M, N] / chunk-major [3, N/32, M, 32]: split output for a following split GEMM); res / res2 float32 [M, N].  float32-grade linear
+        layer on the bf16 matrix cores (csrc/gemm_split3.hip).  Like HipOps.conv, the checked and filled pf_conv_params of a call is cached per
+        (layer, layouts); a repeat call refreshes the data pointers only."""
+        key = (id(pw), x3.shape, x3.stride(), y.shape, y.stride(), y.dtype, act, x3.device,
+               None if res is None else (res.shape, res.stride()), None if res2 is None else (res2.shape, res2.stride()))
+        ent = _CONV_CACHE.get(key)
+        if ent is None or ent[0] is not pw:
+            if len(_CONV_CACHE) > 4096:
+                _CONV_CACHE.clear()
+            ent = (pw, HipOps._conv_split3_plan(x3, pw, y, act, res, res2))
+            _CONV_CACHE[key] = ent
+        else:
+            p = ent[1]
+            p.x, p.y = x3.data_ptr(), y.data_ptr()
+            if res is not None:
+                p.res = res.data_ptr()
+            if res2 is not None:
+                p.res2 = res2.data_ptr()
+        p = ent[1]
         if _timed is not None:
             ms = C.c_float(0)
             check(_L.pf_gemm_split3_timed(C.byref(p), int(_timed), C.byref(ms), _stream()), "pf_gemm_split3_timed")
@@ -412,12 +484,11 @@ class HipOps:
             return
         D = qkv.shape[1] // 3
         assert D == heads * 64 and qkv.is_contiguous() and out.is_contiguous()
-        import os
         if qkv.dtype == torch.float32 and out.dtype == torch.bfloat16:
             assert tuple(out.shape) == ((3, D // 32, B * S, 32) if kmaj else (3, B * S, D))
             check(_L.pf_vit_attention_qkv_split3(_p(qkv), _p(out), out.stride(0), kmaj, B, S, heads, _stream()), "pf_vit_attention_qkv_split3")
             return
-        if qkv.dtype == torch.float32 and os.environ.get("PF_ATTN_QKV", "1") != "0":
+        if qkv.dtype == torch.float32 and _env("PF_ATTN_QKV", "1") != "0":
             # f32: the attention kernel reads q / k / v rows straight out of the QKV GEMM's output (csrc/vit.hip, version 2)
             check(_L.pf_vit_attention_qkv(_p(qkv), _p(out), B, S, heads, 0, _stream()), "pf_vit_attention_qkv")
             return

@@ -201,7 +201,27 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
 
     def _apply(self, fn, *a, **k):
         self._engine = None
+        self._forget_engine_state(release=True)
         return super()._apply(fn, *a, **k)
+
+    def _forget_engine_state(self, release=False):
+        """library-side state tied to an engine: the cached PF_* switches and per-layer dispatch plans of hip_ops (they reference the packed layers
+        of the engine that made them) and, on `release`, the per-stream Winograd arenas (12 + 8 GB per stream at the headline layer: moving the
+        module -- .cpu(), .to(other) -- or calling release_workspaces() returns them to the allocator; they re-grow on demand)."""
+        import sys
+        h = sys.modules.get("patchfusion_amd.hip_ops")
+        if h is not None:
+            h.refresh_env()
+            if release:
+                h.release_workspaces()
+
+    @staticmethod
+    def release_workspaces():
+        """free the engine's per-stream scratch arenas (see hip_ops.release_workspaces); safe at any time between forward calls"""
+        import sys
+        h = sys.modules.get("patchfusion_amd.hip_ops")
+        if h is not None:
+            h.release_workspaces()
 
     def get_save_dict(self):
         return OrderedDict((k, v) for k, v in self.state_dict().items() if 'coarse_branch' not in k and 'fine_branch' not in k)
@@ -231,6 +251,7 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
             if self._ops is None and dev.type != "cuda":
                 raise RuntimeError("PatchFusion (MI355X engine) needs the model on a GPU: call .cuda() first")
             dt, cfg = self.compute_dtype, self.config
+            self._forget_engine_state()                       # PF_* switches are resolved here, once per engine build; cached plans of a previous engine go
             def branch(prefix, bcfg, provider):
                 if bcfg.type == 'ZoeDepth':
                     return ExternalCoreBranchNet(sd, prefix, bcfg, self.patch_process_shape, dt, dev, provider)

@@ -109,9 +109,9 @@ def winograd_applies(pc, pixels, stride, pad, act):
     """call-time half of the eligibility: the layer was packed with Winograd filters and this call is a 3x3 / stride 1 / pad 1
     convolution over at least PF_WINOGRAD_MIN_PIXELS pixels (default 0: measured 1.4 .. 4x the direct kernel on every eligible layer of the pass, from 8x392x518 down to 1x14x19, profiles/r2c_wino_tune.log) whose
     epilogue the output transform implements (bias, ReLU, residuals)."""
-    import os
     if (pc.wino_u is None and pc.wino_up is None) or stride != 1 or pad != 1 or act not in (None, "none", "relu"):
         return False
+    import os
     return pixels >= int(os.environ.get("PF_WINOGRAD_MIN_PIXELS", "0"))
 
 

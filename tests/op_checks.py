@@ -18,6 +18,12 @@ def hip():
     return ops
 
 
+def _switches_changed():
+    """hip_ops resolves its PF_* switches and per-layer dispatch plans once (refresh_env): checks that flip a switch between calls say so"""
+    from patchfusion_amd import hip_ops
+    hip_ops.refresh_env()
+
+
 def _rand(shape, dtype, seed, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return (torch.randn(shape, generator=g) * scale).to(dtype).to(DEV)
@@ -74,6 +80,7 @@ def conv_winograd(dt):
         os.environ["PF_WINOGRAD_MIN_PIXELS"] = "0"
         for m in (2, 4):
             os.environ["PF_WINOGRAD"] = str(m)
+            _switches_changed()
             for i, (B, H, W, cin, cout, kw) in enumerate((
                     (2, 37, 41, 128, 160, dict(act="relu")),
                     (1, 64, 64, 256, 128, dict(relu_in=True, res=True, res2=True)),
@@ -100,6 +107,7 @@ def conv_winograd(dt):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+        _switches_changed()
     torch.cuda.synchronize()
     return max(errs), 8e-6, "winograd F(2,3) / F(4,3) vs direct f32"
 
@@ -125,6 +133,7 @@ def conv_winograd_fused(dt):
                 (1, 392, 518, 128, 32, 8, dict(act="relu")),
                 (2, 112, 148, 256, 256, 5, dict(relu_in=True, act="relu", res=True)))):
             os.environ["PF_WINO_GS"] = str(gs)
+            _switches_changed()
             g = torch.Generator().manual_seed(100 + i)
             w = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
             pw = pk.pack_conv(w, torch.randn(cout, generator=g), dtype=torch.float32).to(DEV)
@@ -136,6 +145,7 @@ def conv_winograd_fused(dt):
             outs = []
             for o, direct, fused in ((hip(), None, "2"), (hip(), None, "0"), (ref_ops, True, "0")):
                 os.environ["PF_WINO_FUSED"] = fused
+                _switches_changed()
                 yb = torch.zeros((B, H, W, cout + 16), dtype=torch.float32, device=DEV)
                 o.conv(x, pw, yb[..., 8:8 + cout], pad=1, act=kw.get("act"), relu_in=kw.get("relu_in", False), res=r1, res2=r2, _direct=direct)
                 outs.append(yb)
@@ -148,6 +158,7 @@ def conv_winograd_fused(dt):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+        _switches_changed()
     torch.cuda.synchronize()
     return max(max(errs), max(errs3)), 3.2e-5, f"fused winograd F(4,3) vs direct f32 (max {max(errs):.2e}) and vs three-step (max {max(errs3):.2e})"
 
@@ -290,9 +301,11 @@ def conv_bf16_pp(dt):
         errs = []
         for flag in ("1", "0"):
             os.environ["PF_BF16_PP"] = flag
+            _switches_changed()
             e, tol, _ = _conv_case(dt, c["B"], c["H"], c["W"], c["cin"], c["cout"], c["k"], **{k: v for k, v in c.items() if k not in ("B", "H", "W", "cin", "cout", "k")})
             errs.append(e)
         os.environ.pop("PF_BF16_PP", None)
+        _switches_changed()
         worst = max(worst, errs[0])
         info.append(f"{c['cin']}->{c['cout']} M={c['B'] * c['H'] * c['W']}: pp {errs[0]:.2e} igemm {errs[1]:.2e}")
     return worst, _tol(dt), "; ".join(info)
@@ -388,6 +401,7 @@ def vit_attention_split(dt):
     import os
     old = os.environ.get("PF_ATTN_QKV")
     os.environ["PF_ATTN_QKV"] = "0"
+    _switches_changed()
     try:
         return vit_attention(dt)
     finally:
@@ -395,6 +409,7 @@ def vit_attention_split(dt):
             os.environ.pop("PF_ATTN_QKV", None)
         else:
             os.environ["PF_ATTN_QKV"] = old
+        _switches_changed()
 
 
 def vit_attention_split3(dt):

@@ -45,7 +45,10 @@ def test_fused_versus_three_step_rule(monkeypatch):
     for v in ("PF_WINO_FUSED", "PF_WINO_SPLIT3", "PF_WINO_FUSED_SMALL"):
         monkeypatch.delenv(v, raising=False)
     p544, p768, p768_256, p64_32 = _pack(544, 544), _pack(768, 768), _pack(256, 768), _pack(32, 64)
-    fw = hip_ops._fused_wanted
+
+    def fw(*a):                      # (the switches are resolved once and cached: a test that flips them says so)
+        hip_ops.refresh_env()
+        return hip_ops._fused_wanted(*a)
     assert not fw(8, 392, 518, p544) and not fw(8, 224, 296, p768)          # >= 512 output channels: three steps with the split GEMM
     assert fw(8, 224, 296, p768_256) and fw(8, 392, 518, p64_32)            # fewer: fused kernel
     assert not fw(1, 28, 37, p768_256) and not fw(1, 56, 74, p64_32)        # too few blocks: three-step / direct

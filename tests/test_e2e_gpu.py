@@ -2,11 +2,13 @@
  (a) the committed golden fixtures generated from the REFERENCE's own Python (tests/golden/*.npz),
  (b) the oracle restatement (oracle/pf_oracle.py) on the same seeded inputs.
 Stated tolerances on the final metric depth, in DEPTH UNITS (synthetic-weight nets: depths 0.4..1.0, std 0.011..0.014):
-   fp32 mode: max |d - ref| <= 2e-4 (f32 MFMA = exact fma chain; only summation order differs; measured ~1e-6..1e-5)
+   fp32 mode: max |d - ref| <= F32_TOL = 5e-5 (float32-grade arithmetic everywhere; only summation order differs; measured ~1e-6 .. 1e-5 --
+              round 3 asserted 2e-4 here, 20-200x the measurement: a 50x numerical regression would have passed)
    bf16 mode: max |d - ref| <= 5e-3 and mean |d - ref| <= 6e-4 = 2x the error measured in round 2 (tiny: max 1.7e-3 / mean
               2.6e-4; ViT-L tiles: max 2.4e-3 / mean 3.1e-4; the configuration the bench times: tests/test_headline_parity_gpu.py)
 """
 BF16_MAX, BF16_MEAN = 5e-3, 6e-4
+F32_TOL = 5e-5
 import os
 import random
 
@@ -43,7 +45,7 @@ def test_tiny_fp32_matches_reference_golden(golden_dir, mode):
     ref = g[f"depth_{mode}"]
     assert tuple(d.shape[2:]) == ref.shape
     err = np.abs(d[0, 0].cpu().numpy() - ref).max()
-    assert err <= 2e-4, f"{mode}: {err}"
+    assert err <= F32_TOL, f"{mode}: {err}"
 
 
 def test_vitb_tiny_fp32_vs_oracle():
@@ -53,7 +55,7 @@ def test_vitb_tiny_fp32_vs_oracle():
     lr = m.resizer(img)
     d, _ = m(mode="infer", image_lr=lr.cuda(), image_hr=img.cuda(), cai_mode="m1", process_num=4)
     ref = pf_oracle.Oracle(cfg, sd).infer(lr, img, "m1", 4)
-    assert float((d.cpu() - ref).abs().max()) < 2e-4
+    assert float((d.cpu() - ref).abs().max()) < F32_TOL
 
 
 def test_tiny_fp32_stage_parity_vs_oracle():
@@ -67,7 +69,7 @@ def test_tiny_fp32_stage_parity_vs_oracle():
         assert (ot[k] - et[k].float().cpu()).abs().max() < 1e-3, k
     for i, (a, b) in enumerate(zip(of, st["feats"])):
         assert (a - nchw(b)).abs().max() < 2e-3, i
-    assert (od - st["depth"].cpu()).abs().max() < 2e-4
+    assert (od - st["depth"].cpu()).abs().max() < F32_TOL
     g2l = pf_oracle.g2l_all(sd, of)
     for i, (a, b) in enumerate(zip(g2l, st["g2l"])):
         assert (a - nchw(b)).abs().max() < 2e-3, i
@@ -93,9 +95,9 @@ def test_full_size_vits_fp32_matches_reference_golden(golden_dir):
     random.seed(5621)
     d, _ = m(mode="infer", image_lr=lr, image_hr=img.cuda(), cai_mode="m1", process_num=4)
     v = d.flatten().cpu()[torch.from_numpy(g["depth_m1_idx"])].numpy()
-    assert np.abs(v - g["depth_m1_val"]).max() <= 2e-4
+    assert np.abs(v - g["depth_m1_val"]).max() <= F32_TOL
     c = m._coarse_state["depth"].flatten().cpu()[torch.from_numpy(g["coarse_depth_idx"])].numpy()
-    assert np.abs(c - g["coarse_depth_val"]).max() <= 2e-4
+    assert np.abs(c - g["coarse_depth_val"]).max() <= F32_TOL
 
 
 @pytest.mark.parametrize("name,split,mode", [("c0_2x2_r4", (2, 2), "r4"), ("c1_4x4_m1", (4, 4), "m1")])
@@ -110,7 +112,7 @@ def test_baseline_configs_0_and_1_match_reference_golden(golden_dir, name, split
     d, _ = m(mode="infer", image_lr=lr, image_hr=img.cuda(), cai_mode=mode, process_num=4)
     assert tuple(d.shape[2:]) == tuple(int(v) for v in g[name + "_shape"])
     v = d.flatten().cpu()[torch.from_numpy(g[name + "_idx"])].numpy()
-    assert np.abs(v - g[name + "_val"]).max() <= 2e-4
+    assert np.abs(v - g[name + "_val"]).max() <= F32_TOL
     del m
     torch.cuda.empty_cache()
 
@@ -178,7 +180,7 @@ def test_baseline_pretrain_fine_and_coarse_vs_oracle():
         lr = m.resizer(img)
         d, _ = m(mode="infer", image_lr=lr.cuda(), image_hr=img.cuda(), cai_mode=mode, process_num=2)
         o = pf_oracle.BaselineOracle(bc, ps, raw, split, sd, target).infer(lr, img, mode, 2)
-        assert d.shape == o.shape and float((d.cpu() - o).abs().max()) < 2e-4, (target, float((d.cpu() - o).abs().max()))
+        assert d.shape == o.shape and float((d.cpu() - o).abs().max()) < F32_TOL, (target, float((d.cpu() - o).abs().max()))
 
 
 def test_zoe_midas_core_geometry_r_mode_vs_oracle():
@@ -193,7 +195,7 @@ def test_zoe_midas_core_geometry_r_mode_vs_oracle():
     cores = (StandInCore(11), StandInCore(12))
     img = torch.rand(1, 3, 1536, 2048, generator=torch.Generator().manual_seed(1234)).cuda()
     sdg = {k: v.cuda() for k, v in sd.items()}
-    for dtype, tol in (("fp32", 2e-4), ("bf16", 1e-2)):
+    for dtype, tol in (("fp32", F32_TOL), ("bf16", 1e-2)):
         m = PatchFusion(cfg, compute_dtype=dtype, core_providers=cores).eval()
         m.load_state_dict(sd, strict=True)
         m = m.cuda()
@@ -221,7 +223,7 @@ def test_train_mode_forward_vs_oracle():
     loss_dict, aux = m(mode="train", image_lr=image_lr.cuda(), image_hr=None, crops_image_hr=crops.cuda(), crop_depths=gt.cuda(),
                        bboxs=bboxs.cuda())
     ref_loss, ref_pred = pf_oracle.Oracle(cfg, sd).train_forward(image_lr, crops, gt, bboxs)
-    assert float((aux["depth_pred"].cpu() - ref_pred).abs().max()) < 2e-4
+    assert float((aux["depth_pred"].cpu() - ref_pred).abs().max()) < F32_TOL
     assert abs(float(loss_dict["total_loss"]) - float(ref_loss)) < 1e-3 * max(1.0, abs(float(ref_loss)))
     # degenerate mask: <= 1 valid pixel -> 0 (losses.py:38-40)
     z = m.ops.silog_loss(aux["depth_pred"].contiguous(), torch.zeros_like(aux["depth_pred"]), 1e-3, 80)
@@ -242,7 +244,7 @@ def test_bin_center_variants_fp32_match_reference_golden(golden_dir, kind, atype
     d, _ = m(mode="infer", image_lr=m.resizer(img).cuda(), image_hr=img.cuda(), cai_mode="m1", process_num=2)
     ref = g[f"{kind}_depth_m1"]
     err = np.abs(d[0, 0].cpu().numpy() - ref).max()
-    assert err <= 2e-4 * max(1.0, np.abs(ref).max()), (kind, err)
+    assert err <= F32_TOL * max(1.0, np.abs(ref).max()), (kind, err)
 
 
 def test_baseline_pretrain_train_mode_and_external_core_on_the_engine():
@@ -268,7 +270,7 @@ def test_baseline_pretrain_train_mode_and_external_core_on_the_engine():
         kw = dict(depth_gt=gt.cuda()) if target == "coarse" else dict(crops_image_hr=x.cuda(), crop_depths=gt.cuda())
         loss, aux = m(mode="train", image_lr=x.cuda(), image_hr=None, **kw)
         want, pred = pf_oracle.BaselineOracle(bc, ps, raw, split, sd, target).train_forward(x, gt)
-        assert float((aux["depth_pred"].cpu() - pred).abs().max()) < 2e-4
+        assert float((aux["depth_pred"].cpu() - pred).abs().max()) < F32_TOL
         assert abs(float(loss["total_loss"]) - float(want)) < 1e-3 * max(1.0, abs(float(want))), target
     ps, raw = (96, 128), (384, 512)
     bc = zoe_midas_branch_config(ps)
@@ -283,7 +285,7 @@ def test_baseline_pretrain_train_mode_and_external_core_on_the_engine():
     lr = m.resizer(img)
     d, _ = m(mode="infer", image_lr=lr.cuda(), image_hr=img.cuda(), cai_mode="m1", process_num=2)
     o = pf_oracle.BaselineOracle(bc, ps, raw, split, sd, "fine", core_provider=core).infer(lr, img, "m1", 2)
-    assert d.shape == o.shape and float((d.cpu() - o).abs().max()) < 2e-4
+    assert d.shape == o.shape and float((d.cpu() - o).abs().max()) < F32_TOL
 
 
 def test_configs3_geometry_8x8_tiles_vs_oracle_on_gpu():
@@ -315,7 +317,7 @@ def test_configs3_geometry_8x8_tiles_vs_oracle_on_gpu():
     got = torch.stack([d[0, 0, (t // 8) * 392:(t // 8 + 1) * 392, (t % 8) * 518:(t % 8 + 1) * 518] for t in tiles])
     err = float((got - ref).abs().max())
     print(f"MEASURED 8x8 geometry (configs[3]), 6 of 64 tiles vs oracle: max {err:.3e}")
-    assert err <= 2e-4, err
+    assert err <= F32_TOL, err
     del m, orc, sdg
     torch.cuda.empty_cache()
 

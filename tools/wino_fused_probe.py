@@ -12,7 +12,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from patchfusion_amd import packing as pk          # noqa: E402
-from patchfusion_amd.hip_ops import ops            # noqa: E402
+from patchfusion_amd.hip_ops import ops
+from patchfusion_amd import hip_ops as _hip_ops            # noqa: E402
 from tests.fake_ops import ops as ref_ops          # noqa: E402
 
 DEV = "cuda"
@@ -24,7 +25,9 @@ def rand(shape, seed):
 
 def check():
     os.environ["PF_WINOGRAD"] = "4"
+    _hip_ops.refresh_env()
     os.environ["PF_WINOGRAD_MIN_PIXELS"] = "0"
+    _hip_ops.refresh_env()
     cases = [
         (1, 8, 32, 32, 32, 8, {}),                                   # one super-tile, one channel block, idle upper half
         (1, 8, 32, 32, 64, 8, {}),
@@ -45,6 +48,7 @@ def check():
         t0 = time.time()
         try:
             os.environ["PF_WINO_GS"], os.environ["PF_WINO_SHAPE"] = str(gs & 0xffff), str(gs >> 16)
+            _hip_ops.refresh_env()
             g = torch.Generator().manual_seed(100 + i)
             w = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
             pw = pk.pack_conv(w, torch.randn(cout, generator=g), dtype=torch.float32, cin_total=cin).to(DEV)
@@ -59,6 +63,7 @@ def check():
             outs = []
             for o, direct, fused in ((ops, None, "2"), (ref_ops, True, "0")):
                 os.environ["PF_WINO_FUSED"] = fused
+                _hip_ops.refresh_env()
                 yb = torch.zeros((B, H, W, cout + 16), dtype=torch.float32, device=DEV)
                 o.conv(x, pw, yb[..., 8:8 + cout], pad=1, act=kw.get("act"), relu_in=kw.get("relu_in", False), res=r1, res2=r2, _direct=direct)
                 torch.cuda.synchronize()
@@ -99,7 +104,9 @@ SHAPES = {
 
 def timing(only):
     os.environ["PF_WINOGRAD"] = "4"
+    _hip_ops.refresh_env()
     os.environ["PF_WINOGRAD_MIN_PIXELS"] = "0"
+    _hip_ops.refresh_env()
     for name, (B, H, W, cin, cout) in SHAPES.items():
         if only and name not in only:
             continue
@@ -110,16 +117,21 @@ def timing(only):
         T = B * -(-H // 4) * -(-W // 4)
         fl_w, fl_d = 36 * 2.0 * T * cin * cout, 2.0 * B * H * W * 9 * cin * cout
         os.environ["PF_WINO_FUSED"] = "0"
+        _hip_ops.refresh_env()
         os.environ["PF_WINO_SPLIT3"] = "0"
+        _hip_ops.refresh_env()
         ms3 = ops.conv(x, pw, y, pad=1, act="relu", _timed=3)
         os.environ["PF_WINO_SPLIT3"] = "1"
+        _hip_ops.refresh_env()
         ms3s = ops.conv(x, pw, y, pad=1, act="relu", _timed=3)
         line = (f"{name:14s} B{B} {H}x{W} {cin}->{cout}: three-step {ms3:8.3f} ms ({fl_d / ms3 / 1e9:6.1f} TF/s direct-eq), with the split-precision "
                 f"GEMM {ms3s:8.3f} ms | fused")
         os.environ["PF_WINO_FUSED"] = "2"
+        _hip_ops.refresh_env()
         best = None
         for gs, shp in ((1, 0), (4, 0), (8, 0), (16, 0), (64, 0), (8, 8), (8, 4)):
             os.environ["PF_WINO_GS"], os.environ["PF_WINO_SHAPE"] = str(gs), str(shp)
+            _hip_ops.refresh_env()
             ms = ops.conv(x, pw, y, pad=1, act="relu", _timed=3)
             line += f" gs{gs}{'/sw' + str(shp) if shp else ''}: {ms:.3f}"
             if best is None or ms < best[0]:
@@ -134,7 +146,9 @@ def timing(only):
 def decomp(names):
     """timing decomposition with the kernel's debug switches (results are wrong by construction)"""
     os.environ["PF_WINOGRAD"], os.environ["PF_WINOGRAD_MIN_PIXELS"], os.environ["PF_WINO_FUSED"] = "4", "0", "2"
+    _hip_ops.refresh_env()
     os.environ["PF_WINO_GS"], os.environ["PF_WINO_SHAPE"] = "8", "0"
+    _hip_ops.refresh_env()
     for name in names:
         B, H, W, cin, cout = SHAPES[name]
         w = torch.randn(cout, cin, 3, 3) / (9 * cin) ** 0.5
@@ -146,9 +160,11 @@ def decomp(names):
                           (8, "no MFMA in T waves"), (16, "no MFMA in D waves"), (24, "no MFMA at all"), (30, "barriers only"), (9, "U hot + no T MFMA"),
                           (3, "U hot, no transform")):
             os.environ["PF_WINO_DBG"] = str(dbg)
+            _hip_ops.refresh_env()
             ms = ops.conv(x, pw, y, pad=1, act="relu", _timed=3)
             line += f"\n    dbg {dbg:2d} ({what}): {ms:.3f} ms"
         os.environ["PF_WINO_DBG"] = "0"
+        _hip_ops.refresh_env()
         print(line, flush=True)
 
 
@@ -156,7 +172,9 @@ def timeline(name, blocks=(1, 5)):
     """s_memtime stamps of one block (debug build): per wave entry / prologue / per chunk (T waves: planes 0-3 done, transform done, planes
     done; DMA waves: DMA issued, planes done, DMA landed) / epilogue phases"""
     os.environ["PF_WINOGRAD"], os.environ["PF_WINOGRAD_MIN_PIXELS"], os.environ["PF_WINO_FUSED"] = "4", "0", "2"
+    _hip_ops.refresh_env()
     os.environ["PF_WINO_GS"], os.environ["PF_WINO_SHAPE"] = "8", "0"
+    _hip_ops.refresh_env()
     B, H, W, cin, cout = SHAPES[name]
     pw = pk.pack_conv(torch.randn(cout, cin, 3, 3) / (9 * cin) ** 0.5, torch.zeros(cout), dtype=torch.float32).to(DEV)
     x, y = torch.randn(B, H, W, cin, device=DEV), torch.empty(B, H, W, cout, device=DEV)
@@ -164,6 +182,7 @@ def timeline(name, blocks=(1, 5)):
     for blk in blocks:
         tb = torch.zeros(8 * 256 * 2, dtype=torch.float32, device=DEV)
         os.environ["PF_WINO_DBG"] = str(128 | (blk << 8))
+        _hip_ops.refresh_env()
         ops.conv(x, pw, y, pad=1, act="relu", res2=tb.view(1, 1, 1, -1))
         ops.conv(x, pw, y, pad=1, act="relu", res2=tb.view(1, 1, 1, -1))
         torch.cuda.synchronize()
@@ -181,6 +200,7 @@ def timeline(name, blocks=(1, 5)):
             print(f"  wave {w}: mean interval chunks 2..57: {sum(iv) / len(iv):.0f} cycles")
             print(f"    prologue done {rel(t[w, 1])}, last chunk done {rel(t[w, 249])}, barrier {rel(t[w, 250])}, after write+barrier {rel(t[w, 251])}, {rel(t[w, 252])}, end {rel(t[w, 253])}")
     os.environ["PF_WINO_DBG"] = "0"
+    _hip_ops.refresh_env()
 
 
 if __name__ == "__main__":
@@ -195,6 +215,7 @@ if __name__ == "__main__":
         sys.exit(0)
     if mode == "one":            # N launches of one shape (for rocprofv3 --pmc passes)
         os.environ["PF_WINOGRAD"], os.environ["PF_WINOGRAD_MIN_PIXELS"], os.environ["PF_WINO_FUSED"] = "4", "0", os.environ.get("PF_WINO_FUSED", "2")
+        _hip_ops.refresh_env()
         B, H, W, cin, cout = SHAPES[sys.argv[2]]
         pw = pk.pack_conv(torch.randn(cout, cin, 3, 3) / (9 * cin) ** 0.5, torch.zeros(cout), dtype=torch.float32).to(DEV)
         x, y = torch.randn(B, H, W, cin, device=DEV), torch.empty(B, H, W, cout, device=DEV)

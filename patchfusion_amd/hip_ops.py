@@ -108,7 +108,7 @@ def _fused_wanted(B, H, W, pw):
     2 = fused wherever supported, 1 (default) = the measured rule (profiles/r3_wino_fused_layers.log, r3_three_step_split.log; 1x MI355X):
     the fused kernel needs at least two rounds of blocks, and it loses to the three-step form on layers with MANY OUTPUT CHANNELS -- each of
     the ceil(Cout/64) channel blocks repeats the input transform, while the batched GEMM of the three-step form runs near its peak there:
-    with the split-precision GEMM from 512 output channels on (544->544 @ 8x392x518: 20.7 vs 22.5 ms; 768->768 @ 8x224x296: 10.3 vs 13.5),
+    with the split-precision GEMM from 256 output channels on (round 3: 512; 544->544 @ 8x392x518: 16.3 vs 22.5 ms; 768->768 @ 8x224x296: 8.4 vs 13.5),
     with the f32 GEMM only at 768+ -> 768+ (13.0 vs 13.5).  Below that the fused kernel wins 1.1x (768->256) ... 2.4x (-> 32 channels)."""
     mode = _env("PF_WINO_FUSED", "1")
     if mode == "0":
@@ -120,7 +120,9 @@ def _fused_wanted(B, H, W, pw):
     if pw.wino_u is None:
         many_out = False                                    # fused-only layer: the alternative is the direct kernel
     elif _split3_three_step(pw):
-        many_out = pw.cout >= 512
+        # round 4 (persistent split GEMM on chunk-major planes, profiles/r4_fused_vs_three_step.md): three steps win 1.04 .. 1.9x from 256 output
+        # channels on (768->256 @ 8x224x296: 3.87 vs 4.84 ms), the fused kernel keeps 256->128 (0.91x) and the 32-channel layers (0.4x)
+        many_out = pw.cout >= 256
     else:
         many_out = pw.cin >= 768 and pw.cout >= 768
     return nsuper * -(-pw.cout // 64) >= 512 and not many_out

@@ -49,11 +49,12 @@ def test_fused_versus_three_step_rule(monkeypatch):
     def fw(*a):                      # (the switches are resolved once and cached: a test that flips them says so)
         hip_ops.refresh_env()
         return hip_ops._fused_wanted(*a)
-    assert not fw(8, 392, 518, p544) and not fw(8, 224, 296, p768)          # >= 512 output channels: three steps with the split GEMM
-    assert fw(8, 224, 296, p768_256) and fw(8, 392, 518, p64_32)            # fewer: fused kernel
+    assert not fw(8, 392, 518, p544) and not fw(8, 224, 296, p768)          # >= 256 output channels (round 4): three steps with the split GEMM
+    assert not fw(8, 224, 296, p768_256)
+    assert fw(8, 224, 296, _pack(128, 256)) and fw(8, 392, 518, p64_32)     # fewer: fused kernel
     assert not fw(1, 28, 37, p768_256) and not fw(1, 56, 74, p64_32)        # too few blocks: three-step / direct
     monkeypatch.setenv("PF_WINO_SPLIT3", "0")                               # f32 GEMM: the old rule (only 768+ -> 768+ stays three-step)
-    assert fw(8, 392, 518, p544) and not fw(8, 224, 296, p768)
+    assert fw(8, 392, 518, p544) and not fw(8, 224, 296, p768) and fw(8, 224, 296, p768_256)
     monkeypatch.setenv("PF_WINO_FUSED", "0")
     assert not fw(8, 392, 518, p544) and not fw(8, 392, 518, p64_32)
     monkeypatch.setenv("PF_WINO_FUSED", "2")

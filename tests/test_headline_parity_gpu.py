@@ -48,7 +48,8 @@ FEATURE_REL_RMS = 1e-5
 # near a tie between bins move by up to 0.05 in bf16 (measured max 0.053, p99 7.7e-3, mean 1.3e-3); budget = 2x measured.  The same
 # sensitivity shows in f32: two f32 evaluations that differ only in summation order (engine vs torch/MIOpen on the GPU) agree
 # to 1.6e-4 max / 3.0e-5 p99 / 5.1e-6 mean on this map while the final map agrees to 1.0e-5.
-TOL_COARSE = {"fp32": dict(max=5e-4, p99=1e-4, mean=2e-5), "bf16": dict(max=0.11, p99=1.6e-2, mean=2.6e-3)}
+# (round 4: 9.8e-6 / 2.3e-6 / 4.3e-7 measured in f32 with every GEMM in split precision or on the f32 MFMA; budget ~10x)
+TOL_COARSE = {"fp32": dict(max=1e-4, p99=2e-5, mean=4e-6), "bf16": dict(max=0.11, p99=1.6e-2, mean=2.6e-3)}
 TOL_COARSE["fp32_mfma_only"] = TOL_COARSE["fp32"]
 
 

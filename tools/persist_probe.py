@@ -88,6 +88,32 @@ def sustain():
     os.environ.pop("PF_S3_PERSIST", None)
 
 
+def layers():
+    """whole 3x3 layers below 512 output channels: the fused f32-MFMA Winograd kernel (csrc/wino_fused.hip) against the three-step form with the
+    split-precision GEMM (round 4: persistent, chunk-major) -- the data behind hip_ops._fused_wanted"""
+    from patchfusion_amd import hip_ops
+    print("\n| 3x3 layer @ B=8 | fused f32-MFMA kernel ms | three-step, split GEMM ms | ratio |")
+    print("|---|---|---|---|")
+    g = torch.Generator().manual_seed(0)
+    for (cin, cout, H, W) in ((768, 256, 224, 296), (512, 256, 224, 296), (256, 256, 224, 296), (256, 128, 224, 296), (256, 256, 196, 259),
+                              (768, 256, 112, 148), (512, 256, 112, 148), (256, 256, 112, 148), (256, 256, 98, 129), (544, 32, 392, 518),
+                              (128, 32, 392, 518), (512, 256, 56, 74), (768, 256, 56, 74), (256, 256, 56, 74)):
+        w = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+        pw = pk.pack_conv(w, torch.zeros(cout), dtype=torch.float32).to(DEV)
+        x = torch.randn(8, H, W, cin, device=DEV)
+        y = torch.empty(8, H, W, cout, device=DEV)
+        t = {}
+        for mode in ("2", "0"):
+            os.environ["PF_WINO_FUSED"] = mode
+            hip_ops.refresh_env()
+            t[mode] = ops.conv(x, pw, y, pad=1, act="relu", _timed=5)
+        os.environ.pop("PF_WINO_FUSED")
+        hip_ops.refresh_env()
+        print(f"| {cin}->{cout} @ {H}x{W} | {t['2']:.3f} | {t['0']:.3f} | {t['2'] / t['0']:.2f} |")
+        del x, y
+        torch.cuda.empty_cache()
+
+
 def decomp():
     """timing decomposition of the persistent kernel on the dominant launch (debug build: PF_LIB_PATH=patchfusion_amd/libpf_wfdbg.so; results are
     wrong by construction): PF_S3_DBG bit 0 = no DMA after the ring fill, bit 1 = no MFMA, bit 2 = no fragment reads, bit 3 = no stores"""
@@ -161,3 +187,5 @@ if __name__ == "__main__":
         timeline()
     if "decomp" in what:
         decomp()
+    if "layers" in what:
+        layers()

@@ -771,48 +771,46 @@ __global__ __launch_bounds__(256, 3) void vit_attention_split3_kernel(const bf16
   // staging roles.  K: item (plane, key, slot): 3 x 64 x 8 = 1536 sixteen-byte items, 6 per thread.  V: item (plane, key pair, slot of 8 d):
   // 3 x 32 x 8 = 768, 3 per thread: two 16-byte loads (keys 2 j, 2 j + 1), eight 4-byte transposing stores (positions of a key pair are adjacent)
   uint4 kreg[6], vreg[3][2];
-  // per-thread source rows, advanced by one tile per iteration (masks only in the last tile: wave-uniform branch)
-  const bf16_t* kptr[6];
-  const bf16_t* vptr[3];
+  // per-thread source rows as 32-bit element offsets from one wave-uniform base that advances by a tile per iteration (64-bit pointers per
+  // row cost 9 more registers: the kernel sits at the 168-register limit of three blocks per CU and used to spill); masks only in the last tile
+  unsigned koff[6], voff[3];
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     const int it = tid + 256 * i;
-    kptr[i] = base + (it >> 9) * plane_in + (long)((it >> 3) & 63) * rs + D + 8 * (it & 7);
+    koff[i] = (unsigned)((it >> 9) * plane_in + (long)((it >> 3) & 63) * rs + D + 8 * (it & 7));
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int it = tid + 256 * i;
-    vptr[i] = base + (it >> 8) * plane_in + (long)(2 * ((it >> 3) & 31)) * rs + 2 * D + 8 * (it & 7);
+    voff[i] = (unsigned)((it >> 8) * plane_in + (long)(2 * ((it >> 3) & 31)) * rs + 2 * D + 8 * (it & 7));
   }
+  const bf16_t* tbase = base;
   const long tile_step = 64 * rs;
   auto gload = [&](int kt) {
     if (kt + 1 < ntiles) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) kreg[i] = *reinterpret_cast<const uint4*>(kptr[i]);
+      for (int i = 0; i < 6; ++i) kreg[i] = *reinterpret_cast<const uint4*>(tbase + koff[i]);
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        vreg[i][0] = *reinterpret_cast<const uint4*>(vptr[i]);
-        vreg[i][1] = *reinterpret_cast<const uint4*>(vptr[i] + rs);
+        vreg[i][0] = *reinterpret_cast<const uint4*>(tbase + voff[i]);
+        vreg[i][1] = *reinterpret_cast<const uint4*>(tbase + voff[i] + rs);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         const int kg = kt * 64 + (((tid + 256 * i) >> 3) & 63);
         kreg[i] = make_uint4(0, 0, 0, 0);
-        if (kg < S) kreg[i] = *reinterpret_cast<const uint4*>(kptr[i]);
+        if (kg < S) kreg[i] = *reinterpret_cast<const uint4*>(tbase + koff[i]);
       }
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         const int kg = kt * 64 + 2 * (((tid + 256 * i) >> 3) & 31);
         vreg[i][0] = vreg[i][1] = make_uint4(0, 0, 0, 0);
-        if (kg < S) vreg[i][0] = *reinterpret_cast<const uint4*>(vptr[i]);
-        if (kg + 1 < S) vreg[i][1] = *reinterpret_cast<const uint4*>(vptr[i] + rs);
+        if (kg < S) vreg[i][0] = *reinterpret_cast<const uint4*>(tbase + voff[i]);
+        if (kg + 1 < S) vreg[i][1] = *reinterpret_cast<const uint4*>(tbase + voff[i] + rs);
       }
     }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) kptr[i] += tile_step;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) vptr[i] += tile_step;
+    tbase += tile_step;
   };
   auto lstore = [&]() {
 #pragma unroll
@@ -1024,6 +1022,7 @@ extern "C" int pf_layernorm_split3(const float* x, int x_ld, void* y3, int y_ld,
 
 extern "C" int pf_vit_attention_split3(const void* qkv3, long plane_in, void* out3, long plane_out, int kmajor, int B, int S, int Hh, void* stream) {
   if (!qkv3 || !out3 || B <= 0 || S <= 0 || Hh <= 0 || plane_in < (long)B * S * Hh * 192 || plane_out < (long)B * S * Hh * 64) return PF_ERR_ARG;
+  if (2 * plane_in + 64L * Hh * 192 + Hh * 192 >= (1L << 32)) return PF_ERR_ARG;          // (32-bit row offsets inside one 64-key tile, three planes)
   const float qscale = 0.125f * 1.4426950408889634f;        // head_dim^-1/2 (attention.py:55) times log2(e): base-2 softmax
   hipLaunchKernelGGL(vit_attention_split3_kernel, dim3((S + 63) / 64, B * Hh), dim3(256), 0, ST(stream), (const bf16_t*)qkv3, plane_in, (bf16_t*)out3,
                      plane_out, B, S, Hh, qscale, kmajor ? (long)B * S : 0L);

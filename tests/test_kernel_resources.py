@@ -80,3 +80,24 @@ def test_fused_winograd_kernel_resources_and_hand_counted_vmem(tmp_path):
     assert len(loops) == 4, report
     shapes = sorted((st["depth"], tuple(sorted(set(st["waits"])))) for _, st in loops)
     assert shapes == [(9, (8,)), (9, (8,)), (14, (9, 13)), (14, (9, 13))], shapes
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
+@pytest.mark.parametrize("src_name,min_kernels", [("gemm_split3.hip", 6), ("vit.hip", 14)])
+def test_split_precision_and_vit_kernels_have_no_scratch(tmp_path, src_name, min_kernels):
+    """csrc/gemm_split3.hip (210 - 251 VGPRs: two 72-register fragment sets + accumulators at two waves per SIMD) and csrc/vit.hip (the split
+    attention kernel runs three blocks per CU = 168 registers and spilled 12 B/lane in round 3): no scratch anywhere, at most 256 registers"""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(ROOT, "patchfusion_amd", "csrc", src_name)
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result", "-c", src,
+                        "-o", str(tmp_path / "k.o"), "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    names = re.findall(r"Function Name: (\S+)", r.stderr)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+    vgprs = [int(x) for x in re.findall(r"VGPRs: (\d+)", r.stderr)]
+    assert len(names) == len(scratch) == len(vgprs) and len(names) >= min_kernels, names
+    assert not any(scratch), {n: s for n, s in zip(names, scratch) if s}
+    assert max(vgprs) <= 256, dict(zip(names, vgprs))
+    if src_name == "vit.hip":
+        att = [v for n, v in zip(names, vgprs) if "vit_attention_split3_kernel" in n]
+        assert att and att[0] <= 168, att          # three blocks per CU

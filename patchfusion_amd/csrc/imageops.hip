@@ -281,38 +281,54 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const void* __restrict__
   const long base = (long)b * H * W;
   const long row_pix = ((long)k * oh + ph) * ow;
   const float y_row = __fadd_rn(start_h, __fmul_rn((float)ph, bin_h));
-  const int items = ow * cv;
+  // a thread owns RUN consecutive output columns of one 8-channel vector and keeps the four tap vectors of the last sample: with the up-sampling
+  // ROIs of this path (a 1/16 region onto the full map: four output columns per source column, one sample per bin) three of four samples reuse
+  // them -- the flat form re-fetched 4 KB of taps through the vector cache for every KB it stored, and THAT bounded it, not HBM
+  constexpr int RUN = 4;
+  const int groups = (ow + RUN - 1) / RUN;
+  const int items = groups * cv;
   for (int i = threadIdx.x; i < items; i += blockDim.x) {
-    const int pw = i / cv, v = i - pw * cv;
-    const float x_col = __fadd_rn(start_w, __fmul_rn((float)pw, bin_w));
-    float acc[8];
+    const int pg = i / cv, v = i - pg * cv;
+    int c_yl = -1, c_xl = -1, c_yh = -1, c_xh = -1;
+    float v1[8], v2[8], v3[8], v4[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    for (int iy = 0; iy < gh; ++iy) {
-      const float yy = __fadd_rn(y_row, __fdiv_rn(__fmul_rn((float)iy + 0.5f, bin_h), (float)gh));
-      for (int ix = 0; ix < gw; ++ix) {
-        float xx = __fadd_rn(x_col, __fdiv_rn(__fmul_rn((float)ix + 0.5f, bin_w), (float)gw));
-        float y2 = yy;
-        if (y2 < -1.0f || y2 > (float)H || xx < -1.0f || xx > (float)W) continue;
-        if (y2 <= 0.f) y2 = 0.f;
-        if (xx <= 0.f) xx = 0.f;
-        int yl = (int)y2, xl = (int)xx, yh, xh;
-        if (yl >= H - 1) { yh = yl = H - 1; y2 = (float)yl; } else yh = yl + 1;
-        if (xl >= W - 1) { xh = xl = W - 1; xx = (float)xl; } else xh = xl + 1;
-        const float ly = y2 - yl, lx = xx - xl, hy = 1.f - ly, hx = 1.f - lx;
-        const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-        float v1[8], v2[8], v3[8], v4[8];
-        ld8x<T>(feat, (base + (long)yl * W + xl) * f_ld + v * 8, in_f32, v1);
-        ld8x<T>(feat, (base + (long)yl * W + xh) * f_ld + v * 8, in_f32, v2);
-        ld8x<T>(feat, (base + (long)yh * W + xl) * f_ld + v * 8, in_f32, v3);
-        ld8x<T>(feat, (base + (long)yh * W + xh) * f_ld + v * 8, in_f32, v4);
+    for (int q = 0; q < RUN; ++q) {
+      const int pw = pg * RUN + q;
+      if (pw >= ow) break;
+      const float x_col = __fadd_rn(start_w, __fmul_rn((float)pw, bin_w));
+      float acc[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += w1 * v1[e] + w2 * v2[e] + w3 * v3[e] + w4 * v4[e];
+      for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+      for (int iy = 0; iy < gh; ++iy) {
+        const float yy = __fadd_rn(y_row, __fdiv_rn(__fmul_rn((float)iy + 0.5f, bin_h), (float)gh));
+        for (int ix = 0; ix < gw; ++ix) {
+          float xx = __fadd_rn(x_col, __fdiv_rn(__fmul_rn((float)ix + 0.5f, bin_w), (float)gw));
+          float y2 = yy;
+          if (y2 < -1.0f || y2 > (float)H || xx < -1.0f || xx > (float)W) continue;
+          if (y2 <= 0.f) y2 = 0.f;
+          if (xx <= 0.f) xx = 0.f;
+          int yl = (int)y2, xl = (int)xx, yh, xh;
+          if (yl >= H - 1) { yh = yl = H - 1; y2 = (float)yl; } else yh = yl + 1;
+          if (xl >= W - 1) { xh = xl = W - 1; xx = (float)xl; } else xh = xl + 1;
+          const float ly = y2 - yl, lx = xx - xl, hy = 1.f - ly, hx = 1.f - lx;
+          const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+          if (yl != c_yl || xl != c_xl || yh != c_yh || xh != c_xh) {
+            ld8x<T>(feat, (base + (long)yl * W + xl) * f_ld + v * 8, in_f32, v1);
+            ld8x<T>(feat, (base + (long)yl * W + xh) * f_ld + v * 8, in_f32, v2);
+            ld8x<T>(feat, (base + (long)yh * W + xl) * f_ld + v * 8, in_f32, v3);
+            ld8x<T>(feat, (base + (long)yh * W + xh) * f_ld + v * 8, in_f32, v4);
+            c_yl = yl; c_xl = xl; c_yh = yh; c_xh = xh;
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += w1 * v1[e] + w2 * v2[e] + w3 * v3[e] + w4 * v4[e];
+        }
       }
-    }
+      if (count != 1.0f) {                              // (x / 1 == x: the up-sampling ROIs of this path take one sample per bin)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] /= count;
-    st8x<T>(y, (row_pix + pw) * y_ld + v * 8, out_f32, acc);
+        for (int e = 0; e < 8; ++e) acc[e] /= count;
+      }
+      st8x<T>(y, (row_pix + pw) * y_ld + v * 8, out_f32, acc);
+    }
   }
 }
 
@@ -878,7 +894,7 @@ extern "C" int pf_roi_align(const void* feat, int f_ld, int Bf, int H, int W, in
     return ok();
   }
   if (C % 8 || f_ld % 8 || y_ld % 8) return PF_ERR_ARG;
-  if ((long)K * oh >= (1L << 31) || (long)ow * (C / 8) >= (1L << 31)) return PF_ERR_ARG;
+  if ((long)K * oh >= (1L << 31) || (long)(ow / 4 + 1) * (C / 8) >= (1L << 31)) return PF_ERR_ARG;
   const unsigned rows = (unsigned)((long)K * oh);
   if (dtype == PF_DTYPE_BF16)
     hipLaunchKernelGGL(roi_align_kernel<bf16_t>, dim3(rows), dim3(256), 0, ST(stream), feat, f_ld, Bf, H, W, C, rois, K, y, y_ld, oh, ow, spatial_scale, in_f32, out_f32);

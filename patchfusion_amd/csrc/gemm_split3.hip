@@ -26,6 +26,7 @@
 // 16-lane groups of ds_read_b128 hit 16 distinct 16-byte positions of the 256-byte bank window (exhaustive check: tools/lds_swizzle_check.py);
 // the DMA writes lane-linearly, so the swizzle is applied on the source side.
 #include <atomic>
+#include <type_traits>
 #include "pf_common.h"
 #include "../../include/pf_hip.h"
 
@@ -334,6 +335,9 @@ __device__ __forceinline__ void glds16s(unsigned voff, unsigned long long sbase,
                : "memory");
 }
 
+// (Measured and NOT kept, round 4: issuing the last 2 .. 6 of a wave's six DMA pieces per chunk from the MFMA phase, spread between the product
+// terms, instead of from the load phase -- 0.97-1.03x on the batched Winograd GEMMs, 0.75-1.18x on the ViT linears, the image pass slower
+// (profiles/r4_p2_sweep.md).  A piece stalls its wave ~95 cycles wherever it is issued; the load phase is what the 192 x 192 kernel below shortens.)
 template <bool BARE>
 __global__ __launch_bounds__(512) void gemm_split3_persist_kernel(const pf_conv_params p, int mt, int nt, int gm, int total) {
   constexpr int BM = 128, BN = 128, WM = 4, WN = 2, NP = 3, NS = 3;
@@ -396,7 +400,9 @@ __global__ __launch_bounds__(512) void gemm_split3_persist_kernel(const pf_conv_
     }
   };
   const unsigned smem_base = lds_addr(smem);
-  int l_load = l_first, l_kc = 0, s_issue = 0;
+  // the loader's cursor is advanced at the HEAD of an issue (ring slot, chunk within the tile, tile switch), always in a load phase
+  int l_load = l_first, l_kc = -1, s_issue = NS - 1;
+  unsigned dst_cur = 0;
   setup_loader(l_load);
 #ifdef PF_S3_DBG           // timing decomposition (results wrong by construction): p.pad bit 0 = no DMA after the first ring fill, bit 1 = no MFMA,
   const int dbg = p.pad;   // bit 2 = no fragment reads after the first, bit 3 = no epilogue stores
@@ -405,24 +411,28 @@ __global__ __launch_bounds__(512) void gemm_split3_persist_kernel(const pf_conv_
 #else
 #define S3P_DBG(bit) 0
 #endif
-  auto issue = [&]() __attribute__((always_inline)) {
-#ifdef PF_S3_DBG
-    if (S3P_DBG(1) && dbg_issued >= NS) return;
-    ++dbg_issued;
-#endif
-    // (readfirstlane: the ring position is wave-uniform by construction, but hipcc's divergence analysis loses that through the tile walk)
-    const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + s_issue * STAGE + wave * (PPW * 1024));
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      glds16s(voff[i], sbase[i], dst + i * 1024);
-      sbase[i] += adv_b;
-    }
+  auto begin_issue = [&]() __attribute__((always_inline)) {
     s_issue = s_issue == NS - 1 ? 0 : s_issue + 1;
     if (++l_kc == nk) {                                  // the stream moves on to this block's next tile
       l_kc = 0;
       l_load += nb;
       if (l_load < hi) setup_loader(l_load);
     }
+    // (readfirstlane: the ring position is wave-uniform by construction, but hipcc's divergence analysis loses that through the tile walk)
+    dst_cur = __builtin_amdgcn_readfirstlane(smem_base + s_issue * STAGE + wave * (PPW * 1024));
+  };
+  auto piece = [&](int i) __attribute__((always_inline)) {
+#ifdef PF_S3_DBG
+    if (S3P_DBG(1) && dbg_issued >= NS * PPW) return;
+    ++dbg_issued;
+#endif
+    glds16s(voff[i], sbase[i], dst_cur + i * 1024);
+    sbase[i] += adv_b;
+  };
+  auto issue = [&]() __attribute__((always_inline)) {    // a whole chunk from the load phase
+    begin_issue();
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) piece(i);
   };
 
   f32x4 acc[FN][FM];
@@ -451,15 +461,15 @@ __global__ __launch_bounds__(512) void gemm_split3_persist_kernel(const pf_conv_
       for (int fm = 0; fm < FM; ++fm) f.x[pl][fm] = *reinterpret_cast<const uint4*>(S + x_off + pl * (BM * 64) + fm * 1024);
     }
   };
-  auto multiply = [&](const Frags& f) __attribute__((always_inline)) {
-    if (S3P_DBG(2)) return;
 #define S3_TERM(PW, PX)                                                                                                      \
   _Pragma("unroll") for (int fn = 0; fn < FN; ++fn) _Pragma("unroll") for (int fm = 0; fm < FM; ++fm)                       \
       acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.w[PW][fn]), __builtin_bit_cast(bf16x8, f.x[PX][fm]), \
                                                             acc[fn][fm], 0, 0, 0);
+  auto multiply = [&](const Frags& f) __attribute__((always_inline)) {
+    if (S3P_DBG(2)) return;
     S3_TERM(0, 2) S3_TERM(2, 0) S3_TERM(1, 1) S3_TERM(0, 1) S3_TERM(1, 0) S3_TERM(0, 0)
-#undef S3_TERM
   };
+#undef S3_TERM
 
   // ---- epilogue of the tile whose last chunk was just multiplied: coordinates decoded in that chunk's load phase, stores one phase later
   int l_comp = l_first, c_kc = 0;
@@ -583,6 +593,273 @@ __global__ __launch_bounds__(512) void gemm_split3_persist_kernel(const pf_conv_
   epilogue();
 }
 
+// ---- PERSISTENT 192 x 192 form (round 4, late) ---------------------------------------------------------------------------------------------------
+// Why: the 128 x 128 kernel above is bounded by its LOAD phase, not by the matrix pipe.  Timeline of the dominant launch (tools/persist_probe.py
+// timeline, profiles/r4_persist_timeline.md): a wave's load phase = 6 LDS-DMA pieces (~95 cycles each wherever they are issued -- moving them
+// among the MFMAs was measured zero-sum, see above) + 18 ds_read_b128 (~16 each) ~= 900 cycles against 48 MFMAs = 768 in the partner's
+// compute phase, so a phase lasts ~1000-1050 cycles and the matrix pipe is busy 73 % of the time (PMC: SQ_VALU_MFMA_BUSY_CYCLES 0.735).
+// A 192 x 192 tile (eight waves of 48 tokens x 96 channels) does 108 MFMAs per wave and chunk (1728 cycles) for 9 pieces + 27 fragment reads
+// (~1300): 2.25x the products for 1.5x the operand bytes, the compute phase is the long one, a third less L2 / HBM operand traffic per product,
+// and N = 544 pads to 576 (5.9 % dead columns) instead of 640 (15 %); 768 = 4 x 192 stays exact.
+// LDS: one stage = 3 planes x (192 + 192) rows x 64 B = 72 KiB, so the ring has TWO slots (144 KiB) and the fragments are SINGLE-buffered in
+// registers (27 x 4 + 72 accumulators; the ping-pong partner covers the LDS latency).  Schedule in global phases (barrier to barrier); group A
+// (waves 0-3, loads the X planes) runs M_A(g) in phase 2g and C_A(g) in phase 2g+1, group B (waves 4-7, the W planes) M_B(g) in 2g+1 and C_B(g) in
+// 2g+2; chunk g lives in slot g & 1:
+//   phase 2h   : EVERY wave issues its pieces of chunk h+1 into slot (h+1) & 1 -- group A at the head of its load phase M_A(h), group B between the
+//                MFMAs of C_B(h-1).  The slot's previous occupant, chunk h-1, was read by A in phase 2h-2 and by B in phase 2h-1, each with
+//                lgkmcnt(0) before the phase's closing barrier.
+//   phase 2h+1 : every wave waits for its own pieces of chunk h+1 (vmcnt(0)) before the closing barrier -- A at the end of C_A(h), B at the end of
+//                M_B(h); A reads chunk h+1 in phase 2h+2, B in 2h+3.
+// (tests/test_split3_schedule_model_cpu.py persist192 replays this control flow and asserts both rules for every chunk count.)
+template <bool BARE>
+__global__ __launch_bounds__(512) void gemm_split3_persist192_kernel(const pf_conv_params p, int mt, int nt, int gm, int total) {
+  constexpr int BM = 192, BN = 192, WM = 4, WN = 2, NP = 3, NS = 2;
+  constexpr int NW = WM * WN;
+  constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 16, FN = WTN / 16;
+  constexpr int ROWS = NP * (BM + BN), PIECES = ROWS / 16, PPW = PIECES / NW;
+  constexpr int STAGE = ROWS * 64;
+  constexpr int NMF = 6 * FN * FM, MPP = NMF / PPW;            // MFMAs per chunk and wave; MFMAs between two pieces of group B
+  static_assert(PPW * 16 * WM == NP * BM && WM * 2 == NW && BM == BN && NMF % PPW == 0, "waves 0..3 stage the X planes, waves 4..7 the W planes");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int M = p.B * p.OH * p.OW;
+  const int nk = p.Cin / 32;
+
+  // ---- this block's tiles (same walk as the 128 x 128 kernel)
+  const int G = (int)gridDim.x, xcd = (int)blockIdx.x & 7, nb = (G - xcd + 7) >> 3;
+  const int lo = (int)((long)total * xcd / 8), hi = (int)((long)total * (xcd + 1) / 8);
+  const int l_first = lo + ((int)blockIdx.x >> 3);
+  if (l_first >= hi) return;
+  const int my_tiles = (hi - l_first + nb - 1) / nb;
+  const int chunks = my_tiles * nk;
+  const int per_plane = mt * nt, per_group = gm * nt;
+  auto decode = [&](int l, int& z, int& m0, int& n0) __attribute__((always_inline)) {
+    z = l / per_plane;
+    const int r = l - z * per_plane;
+    const int group = r / per_group, in_g = r - group * per_group, first = group * gm;
+    const int gsz = min(mt - first, gm);
+    const int tn = in_g / gsz;
+    m0 = (first + in_g - tn * gsz) * BM;
+    n0 = tn * BN;
+  };
+
+  // ---- loader: wave w moves pieces w*PPW .. +PPW-1 of a stage [X h | X m | X l | W h | W m | W l] (12 pieces per plane)
+  const bool is_x = wave < WM;
+  const bool kmaj = (p.korder & (is_x ? 2 : 4)) != 0;
+  const int lim = is_x ? M : p.w_rows;
+  const int ld_b = kmaj ? 64 : (is_x ? p.x_ld : p.Kpad) * 2;
+  const unsigned adv_b = kmaj ? (unsigned)lim * 64u : 64u;
+  const unsigned long long op_base = is_x ? (unsigned long long)p.x : (unsigned long long)p.w;
+  const unsigned long long pl_b = (unsigned long long)(is_x ? p.x_bstride : p.w_bstride) * 2;
+  const unsigned long long z_b = (unsigned long long)lim * ((is_x ? p.x_ld : p.Kpad) * 2);
+  unsigned long long sbase[PPW];
+  unsigned voff[PPW];
+  auto setup_loader = [&](int l) __attribute__((always_inline)) {
+    int z, m0, n0;
+    decode(l, z, m0, n0);
+#ifdef PF_S3_DBG           // traffic experiment (results wrong by construction): p.pad bit 4 = every tile reads the X rows of token tile 0 of plane 0
+    if (p.pad & 16) { m0 = 0; if (is_x) z = 0; }
+#endif
+    const int origin = is_x ? m0 : n0;
+    const unsigned long long tb = op_base + (unsigned long long)z * z_b + (unsigned long long)origin * ld_b;
+    const int last = lim - 1 - origin;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int pc = (wave & (WM - 1)) * PPW + i;                                // piece within this operand's three planes
+      const int row = pc * 16 + (lane >> 2);
+      const int j = (lane & 3) ^ ((row >> 1) & 3);                               // (BM is a multiple of 8: same swizzle as the stage row)
+      const int pl = pc / (BM / 16), r = row - pl * BM;
+      sbase[i] = tb + pl * pl_b;
+      voff[i] = (unsigned)(min(r, last) * ld_b + j * 16);
+    }
+  };
+  const unsigned smem_base = lds_addr(smem);
+  int l_load = l_first, l_kc = -1, s_issue = NS - 1;
+  unsigned dst_cur = 0;
+  setup_loader(l_load);
+  auto begin_issue = [&]() __attribute__((always_inline)) {     // cursor of the next chunk to load: ring slot, chunk within the tile, tile switch
+    s_issue ^= 1;
+    if (++l_kc == nk) {
+      l_kc = 0;
+      l_load += nb;
+      if (l_load < hi) setup_loader(l_load);
+    }
+    dst_cur = __builtin_amdgcn_readfirstlane(smem_base + s_issue * STAGE + wave * (PPW * 1024));
+  };
+  auto piece = [&](int i) __attribute__((always_inline)) {
+    glds16s(voff[i], sbase[i], dst_cur + i * 1024);
+    sbase[i] += adv_b;
+  };
+  auto issue = [&]() __attribute__((always_inline)) {
+    begin_issue();
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) piece(i);
+  };
+
+  f32x4 acc[FN][FM];
+#pragma unroll
+  for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) acc[fn][fm] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fg = lane >> 4;
+  const int slot = (fg ^ ((fr >> 1) & 3)) << 4;
+  const int x_off = (wm * WTM + fr) * 64 + slot;
+  const int w_off = NP * BM * 64 + (wn * WTN + fr) * 64 + slot;
+  struct Frags { uint4 w[NP][FN], x[NP][FM]; };
+  Frags f;
+  int s_read = 0;
+  auto read_frags = [&]() __attribute__((always_inline)) {
+    const char* S = smem + s_read * STAGE;
+    s_read ^= 1;
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn) f.w[pl][fn] = *reinterpret_cast<const uint4*>(S + w_off + pl * (BN * 64) + fn * 1024);
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm) f.x[pl][fm] = *reinterpret_cast<const uint4*>(S + x_off + pl * (BM * 64) + fm * 1024);
+    }
+  };
+  // six partial products, smallest first (the order of gemm_split3_kernel: same bits); ISS: one DMA piece ahead of every MPP-th MFMA
+#define S3_TERM192(TI, PW, PX)                                                                                                  \
+  _Pragma("unroll") for (int fn = 0; fn < FN; ++fn) _Pragma("unroll") for (int fm = 0; fm < FM; ++fm) {                      \
+    if (ISS && ((TI) * FN * FM + fn * FM + fm) % MPP == 0) {                                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                                                       \
+      piece(((TI) * FN * FM + fn * FM + fm) / MPP);                                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                                       \
+    }                                                                                                                          \
+    acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.w[PW][fn]), __builtin_bit_cast(bf16x8, f.x[PX][fm]), \
+                                                          acc[fn][fm], 0, 0, 0);                                               \
+  }
+  auto multiply = [&](auto with_issue) __attribute__((always_inline)) {
+    constexpr bool ISS = decltype(with_issue)::value;
+    S3_TERM192(0, 0, 2) S3_TERM192(1, 2, 0) S3_TERM192(2, 1, 1) S3_TERM192(3, 0, 1) S3_TERM192(4, 1, 0) S3_TERM192(5, 0, 0)
+  };
+#undef S3_TERM192
+
+  int l_comp = l_first, c_kc = 0;
+  int e_z = 0, e_m0 = 0, e_n0 = 0;
+  bool epi_pending = false;
+  auto epilogue = [&]() __attribute__((always_inline)) {
+    const long y_base = (long)e_z * M * p.y_ld;
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) {
+      const int n = e_n0 + wn * WTN + fn * 16 + fg * 4;
+      float4 bias_r = make_float4(0.f, 0.f, 0.f, 0.f), scale_r = make_float4(1.f, 1.f, 1.f, 1.f);
+      if constexpr (!BARE) {
+        __builtin_amdgcn_sched_barrier(0);                 // one channel fragment at a time (register pressure)
+        if (n < p.Cout) {
+          if (p.bias) bias_r = *reinterpret_cast<const float4*>(p.bias + n);
+          if (p.scale) scale_r = *reinterpret_cast<const float4*>(p.scale + n);
+        }
+      }
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm) {
+        const int m = e_m0 + wm * WTM + fm * 16 + fr;
+        if (m < M && n < p.Cout) {
+          if constexpr (BARE) {
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + y_base + (long)m * p.y_ld + n) = acc[fn][fm];
+          } else {
+            float v[4] = {acc[fn][fm][0] + bias_r.x, acc[fn][fm][1] + bias_r.y, acc[fn][fm][2] + bias_r.z, acc[fn][fm][3] + bias_r.w};
+            if (p.act == PF_ACT_RELU) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            } else if (p.act == PF_ACT_GELU) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            } else if (p.act == PF_ACT_SOFTPLUS) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = softplus20(v[r]);
+            }
+            v[0] *= scale_r.x; v[1] *= scale_r.y; v[2] *= scale_r.z; v[3] *= scale_r.w;
+            if (p.res) {
+              const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) + (long)m * p.res_ld + n);
+              v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+            }
+            if (p.res2) {
+              const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res2) + (long)m * p.res2_ld + n);
+              v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+            }
+            if (p.out_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + y_base + (long)m * p.y_ld + n) = make_float4(v[0], v[1], v[2], v[3]);
+            else store_split3(reinterpret_cast<bf16_t*>(p.y) + split3_at(m, n, p.y_ld, (p.korder & 8) ? M : 0), p.y_bstride, v);
+          }
+        }
+        acc[fn][fm] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    epi_pending = false;
+  };
+  auto tile_cursor = [&]() __attribute__((always_inline)) {     // head of a load phase: stores of the finished tile, coordinates of the ending one
+    if (epi_pending) epilogue();                        // beside the partner group's MFMAs
+    if (c_kc == nk - 1) {
+      decode(l_comp, e_z, e_m0, e_n0);
+      l_comp += nb;
+    }
+  };
+  auto tile_advance = [&]() __attribute__((always_inline)) {
+    if (++c_kc == nk) { c_kc = 0; epi_pending = true; }
+  };
+
+  // ---- the chunk stream
+  issue();                                              // chunk 0
+  vm_wait<0>();
+  lds_barrier();
+  if (wave < NW / 2) {
+    // group A: M_A(g) in phase 2g, C_A(g) in phase 2g+1
+#pragma nounroll
+    for (int g = 0; g < chunks; ++g) {
+      tile_cursor();
+      if (g + 1 < chunks) issue();                      // chunk g+1, phase 2g
+      read_frags();
+      lds_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      multiply(std::false_type{});
+      __builtin_amdgcn_s_setprio(0);
+      tile_advance();
+      vm_wait<0>();                                     // this wave's pieces of chunk g+1 have landed (phase 2g+1)
+      plain_barrier();
+    }
+    plain_barrier();                                    // group B's last compute phase
+  } else {
+    // group B: one phase behind; M_B(g) in phase 2g+1, C_B(g) in phase 2g+2
+    if (1 < chunks) issue();                            // chunk 1, phase 0
+    plain_barrier();
+    int g = 0;
+#pragma nounroll
+    for (; g + 2 < chunks; ++g) {
+      tile_cursor();
+      begin_issue();                                    // cursor of chunk g+2 (no memory operation: the pieces follow in the compute phase)
+      read_frags();
+      vm_wait<0>();                                     // pieces of chunk g+1 (issued in phase 2g)
+      lds_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      multiply(std::true_type{});                       // chunk g, with the pieces of chunk g+2 (phase 2g+2)
+      __builtin_amdgcn_s_setprio(0);
+      tile_advance();
+      plain_barrier();
+    }
+#pragma nounroll
+    for (; g < chunks; ++g) {                           // the last two chunks: nothing left to issue
+      tile_cursor();
+      read_frags();
+      vm_wait<0>();
+      lds_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      multiply(std::false_type{});
+      __builtin_amdgcn_s_setprio(0);
+      tile_advance();
+      plain_barrier();
+    }
+  }
+  epilogue();
+}
+
 thread_local char g_err[200] = {0};
 
 int cu_count() {
@@ -625,6 +902,33 @@ int launch_persist(const pf_conv_params& p, hipStream_t st) {
 #endif
   if (bare) hipLaunchKernelGGL(gemm_split3_persist_kernel<true>, dim3((unsigned)grid), dim3(512), smem, st, p, mt, nt, gm, (int)total);
   else hipLaunchKernelGGL(gemm_split3_persist_kernel<false>, dim3((unsigned)grid), dim3(512), smem, st, p, mt, nt, gm, (int)total);
+  return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_LAUNCH;
+}
+
+// persistent 192 x 192 launch (one block per CU, 144 KiB of LDS)
+int launch_persist192(const pf_conv_params& p, hipStream_t st) {
+  constexpr int smem = 2 * 3 * (192 + 192) * 64;
+  static std::atomic<unsigned long long> done{0};
+  int dev = 0;
+  hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split3_persist192_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split3_persist192_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    done.fetch_or(bit, std::memory_order_release);
+  }
+  const long M = (long)p.B * p.OH * p.OW;
+  const int mt = (int)((M + 191) / 192), nt = (p.Cout + 191) / 192;
+  const long total = (long)mt * nt * (p.batch > 1 ? p.batch : 1);
+  const int gm = nt <= 6 ? 32 / nt : 8;
+  int grid = cu_count();
+  if (const char* s = getenv("PF_S3_GRID")) grid = atoi(s);              // (tests: fewer blocks than CUs = more tiles per block; read per call)
+  if (grid > total) grid = (int)total;
+  grid &= ~7;
+  if (grid < 8 || total > 0x7fffffffL) return PF_ERR_ARG;
+  const bool bare = !p.bias && !p.scale && !p.res && !p.res2 && p.act == PF_ACT_NONE && p.out_f32;
+  if (bare) hipLaunchKernelGGL(gemm_split3_persist192_kernel<true>, dim3((unsigned)grid), dim3(512), smem, st, p, mt, nt, gm, (int)total);
+  else hipLaunchKernelGGL(gemm_split3_persist192_kernel<false>, dim3((unsigned)grid), dim3(512), smem, st, p, mt, nt, gm, (int)total);
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_LAUNCH;
 }
 
@@ -684,8 +988,19 @@ extern "C" int pf_gemm_split3(const pf_conv_params* p, void* stream) {
   // from two full rounds of tiles on: the persistent tile walk (one block per CU, chunk stream continuous across tiles); PF_S3_PERSIST=0 = A/B
   const char* ps = getenv("PF_S3_PERSIST");
   const long planes = p->batch > 1 ? p->batch : 1;
-  if (!(ps && ps[0] == '0') && p->Cin >= 96 && (t128 * planes >= 2L * cu_count() || (ps && ps[0] == '2')) && t128 * planes >= 8)
+  if (!(ps && ps[0] == '0') && p->Cin >= 96 && (t128 * planes >= 2L * cu_count() || (ps && ps[0] == '2')) && t128 * planes >= 8) {
+    // 192 x 192 tiles or 128 x 128?  PF_S3_T192: 0 = never, 2 = wherever legal, default = the cheaper by rounds of tiles per CU x cost of a tile:
+    // a 192-tile is 2.25x the products of a 128-tile and runs them ~8 % faster (profiles/r4_t192_sweep.md: 768->768 1.06x, exact in both
+    // tilings), i.e. costs 2.1 -- N = 544 pads to 576 instead of 640 columns (1.15x), 768 / 3072 / 4096 gain 1.05-1.12x, while N <= 256 and
+    // the 8296 x 1024 projections (264 tiles on 256 CUs) stay on 128 x 128
+    const char* ts = getenv("PF_S3_T192");
+    const long t192 = ((M + 191) / 192) * ((p->Cout + 191) / 192);
+    const long cus = cu_count();
+    const long cost128 = ((t128 * planes + cus - 1) / cus) * 100, cost192 = ((t192 * planes + cus - 1) / cus) * 210;
+    const bool want = ts && ts[0] == '2' ? true : (ts && ts[0] == '0' ? false : cost192 < cost128);
+    if (want && t192 * planes >= 8) return launch_persist192(*p, st);
     return launch_persist(*p, st);
+  }
   const char* pp = getenv("PF_S3_PP");                    // (A/B switch; read per call)
   return (pp && pp[0] == '0') ? launch<128, 128, 4, 2, 3, false>(*p, st) : launch<128, 128, 4, 2, 3, true>(*p, st);
 }

@@ -481,12 +481,15 @@ def gemm_split3(dt):
         den = max(1.0, float(ref.abs().max()))
         x3 = torch.empty(3, M, K, dtype=torch.bfloat16, device=DEV)
         o.split3(x, x3)
-        for force in ("64", "128", "persist16", "persist64"):
+        for force in ("64", "128", "persist16", "persist64", "t192_8", "t192_16", "t192_64"):
             # persist<G>: the persistent tile walk (csrc/gemm_split3.hip gemm_split3_persist_kernel) forced on these small shapes with a
-            # G-block grid, so that every block crosses several tile boundaries (ragged last token tile, N = 544 = 4 x 128 + 32)
-            os.environ["PF_S3_TILE_NOW"] = "128" if force.startswith("persist") else force
-            if force.startswith("persist"):
-                os.environ["PF_S3_PERSIST"], os.environ["PF_S3_GRID"] = "2", force[7:]
+            # G-block grid, so that every block crosses several tile boundaries (ragged last token tile, N = 544 = 4 x 128 + 32);
+            # t192_<G>: the same through the 192 x 192 persistent kernel (two-slot ring; N = 544 = 2 x 192 + 160, 1024 = 5 x 192 + 64)
+            pers = force.startswith("persist") or force.startswith("t192")
+            os.environ["PF_S3_TILE_NOW"] = "128" if pers else force
+            os.environ["PF_S3_T192"] = "2" if force.startswith("t192") else "0"
+            if pers:
+                os.environ["PF_S3_PERSIST"], os.environ["PF_S3_GRID"] = "2", force.split("_")[1] if "_" in force else force[7:]
             else:
                 os.environ["PF_S3_PERSIST"] = "0"
             y = torch.zeros(M, N, device=DEV)
@@ -496,7 +499,7 @@ def gemm_split3(dt):
             e1 = float((y.double() - ref).abs().max()) / den
             e3 = float((y3.double().sum(0) - ref).abs().max()) / den
             errs += [e1, e3]
-        for k in ("PF_S3_TILE_NOW", "PF_S3_PERSIST", "PF_S3_GRID"):
+        for k in ("PF_S3_TILE_NOW", "PF_S3_PERSIST", "PF_S3_GRID", "PF_S3_T192"):
             os.environ.pop(k, None)
         yf = torch.zeros(1, 1, M, N, device=DEV)
         o.conv(x.view(1, 1, M, K), pw, yf, act=act, res=r1.view(1, 1, M, N) if res else None, res2=r2.view(1, 1, M, N) if res2 else None)
@@ -579,26 +582,38 @@ def gemm_split3_persist(dt):
         o.gemm_planes_split3(V3, U3, y0, T, cin, cout)
         e0 = float((y0.double() - ref).abs().max()) / den
         same = True
+        os.environ["PF_S3_T192"] = "0"
         for gr in grids:
             os.environ["PF_S3_PERSIST"], os.environ["PF_S3_GRID"] = "2", gr
             y1 = torch.full((P, T, cout), float("nan"), device=DEV)
             o.gemm_planes_split3(V3, U3, y1, T, cin, cout)
             same = same and bool((y1 == y0).all())
+        # the 192 x 192 persistent kernel (two-slot ring): same chunk order and term order per accumulator -> the same bits
+        os.environ["PF_S3_T192"] = "2"
+        same192 = True
+        for gr in grids:
+            os.environ["PF_S3_PERSIST"], os.environ["PF_S3_GRID"] = "2", gr
+            y1 = torch.full((P, T, cout), float("nan"), device=DEV)
+            o.gemm_planes_split3(V3, U3, y1, T, cin, cout)
+            same192 = same192 and bool((y1 == y0).all())
         # chunk-major operands ([plane][point][K/32][rows][32], what csrc/winograd.hip and PackedConv.wino_u3 hand to the kernel): same bits again,
         # through both kernels
         V3k = V3.view(3, P, T, cin // 32, 32).permute(0, 1, 3, 2, 4).contiguous()
         U3k = U3.view(3, P, rows, cin // 32, 32).permute(0, 1, 3, 2, 4).contiguous()
-        for pers, gr in (("0", "0"), ("2", grids[0]), ("2", grids[-1])):
-            os.environ["PF_S3_PERSIST"], os.environ["PF_S3_GRID"] = pers, gr
+        for pers, gr, t192 in (("0", "0", "0"), ("2", grids[0], "0"), ("2", grids[-1], "0"), ("2", grids[0], "2"), ("2", grids[-1], "2")):
+            os.environ["PF_S3_PERSIST"], os.environ["PF_S3_GRID"], os.environ["PF_S3_T192"] = pers, gr, t192
             if gr == "0":
                 os.environ.pop("PF_S3_GRID")
             y1 = torch.full((P, T, cout), float("nan"), device=DEV)
             o.gemm_planes_split3(V3k, U3k, y1, T, cin, cout)
-            same = same and bool((y1 == y0).all())
-        for k in ("PF_S3_TILE_NOW", "PF_S3_PERSIST", "PF_S3_GRID"):
+            if t192 == "2":
+                same192 = same192 and bool((y1 == y0).all())
+            else:
+                same = same and bool((y1 == y0).all())
+        for k in ("PF_S3_TILE_NOW", "PF_S3_PERSIST", "PF_S3_GRID", "PF_S3_T192"):
             os.environ.pop(k, None)
-        info.append(f"P{P} T{T} {cin}->{cout}: err {e0:.2e} persistent==one-tile==chunk-major {same}")
-        worst = max(worst, e0 if same else float("inf"))
+        info.append(f"P{P} T{T} {cin}->{cout}: err {e0:.2e} persistent==one-tile==chunk-major {same} 192-tile kernel identical {same192}")
+        worst = max(worst, e0 if (same and same192) else float("inf"))
     return worst, 2e-6, "; ".join(info)
 
 

@@ -70,23 +70,29 @@ def ring2(nk, wave):
         yield ("mfma", kc)
 
 
-def persist_pingpong(nk, tiles, wave, log):
+PPW = 6          # DMA pieces per wave and chunk
+
+
+def persist_pingpong(nk, tiles, wave, log, p2=0):
     """gemm_split3_persist_kernel (round 4): `tiles` tiles of `nk` chunks each form ONE chunk stream; statement by statement the C++ control flow,
-    with the loader's tile cursor (l_load, l_kc), the compute cursor (l_comp, c_kc) and the deferred epilogue.  `log` collects
-    ("load", g, tile, kc) / ("mfma", g, tile) / ("store", tile) records for the cursor checks."""
+    with the loader's tile cursor (l_load, l_kc, advanced at the head of an issue), the compute cursor (l_comp, c_kc) and the deferred epilogue.
+    p2 > 0: in the steady part of the stream (both chunks of a pair still issue) the last p2 of a wave's six DMA pieces per chunk are issued
+    from the MFMA phase; waits are counted in PIECES there.  `log` collects ("load", g, tile, kc) / ("mfma", g, tile) / ("store", tile) records."""
     NS = 3
     chunks = tiles * nk
-    st = {"l_load": 0, "l_kc": 0, "issued": 0}
+    st = {"l_load": 0, "l_kc": -1, "issued": -1}
 
-    def issue():
-        log.append(("load", st["issued"], st["l_load"], st["l_kc"]))
-        ev = ("issue", st["issued"])
+    def begin_issue():
         st["issued"] += 1
         st["l_kc"] += 1
         if st["l_kc"] == nk:
             st["l_kc"] = 0
             st["l_load"] += 1
-        return ev
+        log.append(("load", st["issued"], st["l_load"], st["l_kc"]))
+
+    def issue():
+        begin_issue()
+        return ("issue", st["issued"])
     for i in range(NS):
         if i < chunks:
             yield issue()
@@ -98,22 +104,38 @@ def persist_pingpong(nk, tiles, wave, log):
     if grp_b:
         yield ("barrier", False)
     l_comp, c_kc, e_tile, epi_pending = 0, 0, None, False
+    n_steady = 0
+    if p2 > 0:
+        g = 0
+        while g + 4 < chunks:
+            n_steady += 2
+            g += 2
     for g in range(chunks):
+        steady = g < n_steady
         if epi_pending:
             log.append(("store", e_tile))
             epi_pending = False
         if c_kc == nk - 1:
             e_tile = l_comp
             l_comp += 1
-        if g + 3 < chunks:
-            yield issue()
-        if g + 1 < chunks:
+        if steady:
+            begin_issue()
+            if PPW - p2:
+                yield ("issuep", st["issued"], PPW - p2)
             yield ("read", g + 1)
-        if g + 3 < chunks:
-            yield ("wait", 1)
-        elif g + 2 < chunks:
-            yield ("wait", 0)
+            yield ("waitp", PPW - p2)
+        else:
+            if g + 3 < chunks:
+                yield issue()
+            if g + 1 < chunks:
+                yield ("read", g + 1)
+            if g + 3 < chunks:
+                yield ("wait", 1)
+            elif g + 2 < chunks:
+                yield ("wait", 0)
         yield ("barrier", True)
+        if steady:
+            yield ("issuep", st["issued"], p2)           # between the MFMAs of this phase
         log.append(("mfma", g, l_comp - 1 if c_kc == nk - 1 else l_comp))
         yield ("mfma", g)
         c_kc += 1
@@ -127,7 +149,79 @@ def persist_pingpong(nk, tiles, wave, log):
     log.append(("store", e_tile))
 
 
-def simulate(schedule, nk, NS):
+def persist192(nk, tiles, wave, log):
+    """gemm_split3_persist192_kernel (round 4, late): 192 x 192 tiles, TWO ring slots, fragments single-buffered; statement by statement the C++
+    control flow of the two wave groups.  Every wave issues its nine pieces of chunk h+1 in global phase 2h (group A from its load phase, group B
+    between the MFMAs of its compute phase) and waits for them at the end of phase 2h+1."""
+    chunks = tiles * nk
+    P = 9
+    st = {"l_load": 0, "l_kc": -1, "issued": -1}
+
+    def begin_issue():
+        st["issued"] += 1
+        st["l_kc"] += 1
+        if st["l_kc"] == nk:
+            st["l_kc"] = 0
+            st["l_load"] += 1
+        log.append(("load", st["issued"], st["l_load"], st["l_kc"]))
+
+    cur = {"l_comp": 0, "c_kc": 0, "e_tile": None, "epi": False}
+
+    def tile_cursor():
+        if cur["epi"]:
+            log.append(("store", cur["e_tile"]))
+            cur["epi"] = False
+        if cur["c_kc"] == nk - 1:
+            cur["e_tile"] = cur["l_comp"]
+            cur["l_comp"] += 1
+
+    def mfma(g):
+        log.append(("mfma", g, cur["l_comp"] - 1 if cur["c_kc"] == nk - 1 else cur["l_comp"]))
+        cur["c_kc"] += 1
+        if cur["c_kc"] == nk:
+            cur["c_kc"] = 0
+            cur["epi"] = True
+        return ("mfma", g)
+
+    begin_issue()
+    yield ("issuep", 0, P)
+    yield ("waitp", 0)
+    yield ("barrier", True)
+    if wave < NW // 2:
+        for g in range(chunks):
+            tile_cursor()
+            if g + 1 < chunks:
+                begin_issue()
+                yield ("issuep", g + 1, P)
+            yield ("read", g)
+            yield ("barrier", True)
+            yield mfma(g)
+            yield ("waitp", 0)
+            yield ("barrier", False)
+        yield ("barrier", False)
+    else:
+        if 1 < chunks:
+            begin_issue()
+            yield ("issuep", 1, P)
+        yield ("barrier", False)
+        for g in range(chunks):
+            steady = g + 2 < chunks
+            tile_cursor()
+            if steady:
+                begin_issue()
+            yield ("read", g)
+            yield ("waitp", 0)
+            yield ("barrier", True)
+            if steady:
+                yield ("issuep", g + 2, P)
+            yield mfma(g)
+            yield ("barrier", False)
+    assert cur["epi"]
+    log.append(("store", cur["e_tile"]))
+
+
+def simulate(schedule, nk, NS, ppw=None):
+    ppw = ppw or PPW
     gens = [schedule(nk, w) for w in range(NW)]
     issued = [[] for _ in range(NW)]             # per wave: chunks in issue order (in-order DMA queue)
     landed_phase = [dict() for _ in range(NW)]   # per wave: chunk -> phase in which the wave waited for its pieces
@@ -149,13 +243,16 @@ def simulate(schedule, nk, NS):
                 except StopIteration:
                     alive[w] = False
                     break
-                if ev[0] == "issue":
-                    issued[w].append(ev[1])
-                    issue_phase[w][ev[1]] = phase
-                elif ev[0] == "wait":
-                    done = issued[w][:len(issued[w]) - ev[1]] if ev[1] else issued[w]
-                    for c in done:
-                        landed_phase[w].setdefault(c, phase)
+                if ev[0] in ("issue", "issuep"):                 # ("issue", chunk) = all six pieces; ("issuep", chunk, k) = k of them
+                    k = ppw if ev[0] == "issue" else ev[2]
+                    issued[w] += [ev[1]] * k
+                    issue_phase[w].setdefault(ev[1], phase)
+                elif ev[0] in ("wait", "waitp"):                 # at most N chunks' worth ("wait") / N pieces ("waitp") may stay in flight
+                    n = ev[1] * ppw if ev[0] == "wait" else ev[1]
+                    done = issued[w][:len(issued[w]) - n] if n else issued[w]
+                    for c in set(done):
+                        if done.count(c) == ppw:
+                            landed_phase[w].setdefault(c, phase)
                 elif ev[0] == "read":
                     assert ev[1] not in read_phase[w], f"chunk {ev[1]} read twice by wave {w}"
                     read_phase[w][ev[1]] = phase
@@ -173,6 +270,7 @@ def simulate(schedule, nk, NS):
     assert len(set(nbar)) == 1, f"waves disagree on the number of barriers: {nbar}"
     for w in range(NW):
         assert mfma[w] == list(range(nk)) and sorted(read_phase[w]) == list(range(nk))
+        assert all(issued[w].count(c) == ppw for c in range(nk)), f"wave {w}: every chunk must be issued as exactly {ppw} pieces"
         for c, ph in read_phase[w].items():                                    # R1
             for v in range(NW):
                 assert c in landed_phase[v] and landed_phase[v][c] < ph, f"R1: wave {w} reads chunk {c} in phase {ph}, wave {v} waited in {landed_phase[v].get(c)}"
@@ -201,13 +299,14 @@ def test_the_model_catches_a_missing_wait():
         simulate(broken, 8, 3)
 
 
+@pytest.mark.parametrize("p2", [0, 3])          # 0 = the kernel; 3 = the measured-and-dropped split issue (kept as a model of a legal variant)
 @pytest.mark.parametrize("nk,tiles", [(1, 1), (1, 5), (2, 3), (3, 1), (3, 4), (4, 3), (17, 1), (17, 2), (17, 9), (32, 7), (5, 8)])
-def test_persistent_tile_walk_is_hazard_free_and_keeps_its_cursors(nk, tiles):
+def test_persistent_tile_walk_is_hazard_free_and_keeps_its_cursors(nk, tiles, p2):
     """the persistent kernel's chunk stream obeys the ring rules R1 / R2 across tile boundaries, the loader's cursor names tile g // nk, chunk
     g % nk for stream position g, every chunk is multiplied into the accumulators of its own tile, and tile t is stored exactly once: after its
     last chunk's MFMAs and before the first MFMAs of tile t + 1"""
     logs = [[] for _ in range(NW)]
-    simulate(lambda n, w: persist_pingpong(nk, tiles, w, logs[w]), nk * tiles, 3)
+    simulate(lambda n, w: persist_pingpong(nk, tiles, w, logs[w], p2), nk * tiles, 3)
     for w in range(NW):
         loads = [r for r in logs[w] if r[0] == "load"]
         assert [(r[1], r[2], r[3]) for r in loads] == [(g, g // nk, g % nk) for g in range(nk * tiles)]
@@ -221,6 +320,41 @@ def test_persistent_tile_walk_is_hazard_free_and_keeps_its_cursors(nk, tiles):
                 assert r[1] == len(stored)
                 stored.append(r[1])
         assert stored == list(range(tiles))
+
+
+@pytest.mark.parametrize("nk,tiles", [(1, 1), (1, 2), (1, 5), (2, 1), (2, 3), (3, 1), (3, 4), (4, 3), (17, 1), (17, 2), (17, 9), (32, 7), (5, 8), (24, 3)])
+def test_persist192_two_slot_ring_is_hazard_free_and_keeps_its_cursors(nk, tiles):
+    """the 192 x 192 persistent kernel: two ring slots, R1 / R2 across tile boundaries for both wave groups (group B issues from its MFMA phase),
+    loader / compute cursors and the deferred stores as in the 128 x 128 kernel"""
+    logs = [[] for _ in range(NW)]
+    simulate(lambda n, w: persist192(nk, tiles, w, logs[w]), nk * tiles, 2, ppw=9)
+    for w in range(NW):
+        loads = [r for r in logs[w] if r[0] == "load"]
+        assert [(r[1], r[2], r[3]) for r in loads] == [(g, g // nk, g % nk) for g in range(nk * tiles)]
+        stored = []
+        for r in [r for r in logs[w] if r[0] != "load"]:
+            if r[0] == "mfma":
+                assert r[2] == r[1] // nk, r
+                assert stored == list(range(r[2])), f"wave {w}: chunk {r[1]} of tile {r[2]} multiplied while tiles {stored} are stored"
+            else:
+                assert r[1] == len(stored)
+                stored.append(r[1])
+        assert stored == list(range(tiles))
+
+
+def test_the_model_catches_an_early_issue_into_the_two_slot_ring():
+    def broken(nk, wave):                       # group B issuing chunk g+2 one phase early (from its load phase) overwrites what it is reading
+        evs = list(persist192(8, 2, wave, []))
+        out = []
+        for i, ev in enumerate(evs):
+            if wave >= NW // 2 and ev[0] == "issuep" and ev[1] >= 2:
+                j = max(k for k in range(len(out)) if out[k][0] == "read")
+                out.insert(j, ev)
+            else:
+                out.append(ev)
+        yield from out
+    with pytest.raises(AssertionError, match="R2"):
+        simulate(broken, 16, 2, ppw=9)
 
 
 def _persist_tiles(mt, nt, planes, G):

@@ -88,8 +88,9 @@ def work(name, a, k):
         return "flop", fl, desc
     if name == "conv_split3":
         x3, pw, y = a[0], a[1], a[2]
-        fl = 2.0 * x3.shape[1] * pw.cin * pw.cout
-        return "flop", fl, (f"(1, 1, {x3.shape[1]}) {pw.cin}->{pw.cout} k1 s1 [split-precision bf16x3]" + (" -> planes" if y.dtype == torch.bfloat16 else "")), SPLIT_PEAK
+        rows = x3.shape[2] if x3.dim() == 4 else x3.shape[1]          # chunk-major planes are [3, K/32, M, 32]
+        fl = 2.0 * rows * pw.cin * pw.cout
+        return "flop", fl, (f"(1, 1, {rows}) {pw.cin}->{pw.cout} k1 s1 [split-precision bf16x3]" + (" -> planes" if y.dtype == torch.bfloat16 else "")), SPLIT_PEAK
     if name == "layernorm_split3":
         x, y3 = a[0], a[1]
         return "byte", nbytes(x) + nbytes(y3), f"rows {x.shape[0]} D{x.shape[1]} -> three bf16 planes"

@@ -175,6 +175,73 @@ def timeline():
     print("(s_memtime ticks = shader clock cycles; the instrumentation itself costs ~10 % of a chunk)")
 
 
+def t192sweep():
+    """the 192 x 192 persistent kernel (two-slot ring, PF_S3_T192=2) against the 128 x 128 one (PF_S3_T192=0) on the same launches"""
+    _sweep((("PF_S3_T192",), ("0", "2")))
+
+
+def _sweep(knob):
+    names, p2s = knob
+    print("| launch | " + " | ".join(f"{names[0]}={v} ms" for v in p2s) + " | best | useful TF/s at best | of 2500/6 |")
+    print("|---|" + "---|" * (len(p2s) + 3))
+    g = torch.Generator(device=DEV).manual_seed(0)
+
+    def row(name, fl, fn):
+        ts = []
+        for v in p2s:
+            for nm in names:
+                os.environ[nm] = v
+            ts.append(fn())
+        for nm in names:
+            os.environ.pop(nm, None)
+        b = min(range(len(ts)), key=lambda i: ts[i])
+        print(f"| {name} | " + " | ".join(f"{t:.3f}" for t in ts) + f" | {names[0]}={p2s[b]} ({ts[0] / ts[b]:.2f}x) | {fl / ts[b] / 1e9:.1f} | {fl / ts[b] / 1e9 / (2500 / 6):.3f} |", flush=True)
+
+    for (cin, cout, B, H, W) in ((544, 544, 8, 392, 518), (768, 768, 8, 224, 296), (768, 256, 8, 224, 296), (512, 256, 8, 224, 296), (256, 256, 8, 224, 296),
+                                 (768, 768, 8, 112, 148), (768, 768, 8, 56, 74)):
+        T = B * -(-H // 4) * -(-W // 4)
+        rows = -(-cout // 16) * 16
+        V3k = torch.randn(3, 36, cin // 32, T, 32, device=DEV, generator=g, dtype=torch.float32).to(torch.bfloat16)
+        U3k = (torch.randn(3, 36, cin // 32, rows, 32, device=DEV, generator=g) / cin ** 0.5).to(torch.bfloat16)
+        Mw = torch.empty(36, T, cout, device=DEV)
+        row(f"wino GEMM {cin}->{cout} @ {B}x{H}x{W}", 36 * 2.0 * T * cin * cout, lambda: ops.gemm_planes_split3(V3k, U3k, Mw, T, cin, cout, 5))
+        del V3k, U3k, Mw
+        torch.cuda.empty_cache()
+    gc = torch.Generator().manual_seed(0)
+    os.environ["PF_S3_PERSIST"] = "2"
+    for M in (8 * 1037, 1037):
+        for name, K, N, act, res, scale, split_out in (("qkv", 1024, 3072, None, False, False, True), ("proj", 1024, 1024, None, True, True, False),
+                                                       ("fc1", 1024, 4096, "gelu", False, False, True), ("fc2", 4096, 1024, None, True, True, False)):
+            w = torch.randn(N, K, generator=gc) / K ** 0.5
+            b = torch.randn(N, generator=gc)
+            sc = (0.5 + torch.rand(N, generator=gc)) if scale else None
+            pw3 = pk.pack_conv_split3(w, b, scale=sc).to(DEV)
+            x3 = torch.randn(3, K // 32, M, 32, generator=gc).to(torch.bfloat16).to(DEV)
+            r = torch.randn(M, N, generator=gc).to(DEV) if res else None
+            y = torch.empty(3, N // 32, M, 32, dtype=torch.bfloat16, device=DEV) if split_out else torch.empty(M, N, device=DEV)
+            row(f"{name} {K}->{N} M={M}", 2.0 * M * K * N, lambda: ops.conv_split3(x3, pw3, y, act=act, res=r, _timed=20))
+    os.environ.pop("PF_S3_PERSIST", None)
+
+
+def traffic():
+    """is the dominant launch bounded by its operand traffic?  (debug build: PF_LIB_PATH=patchfusion_amd/libpf_wfdbg.so; PF_S3_DBG=16 makes every
+    tile of the 192 x 192 kernel read the X rows of ONE token tile -- L2 hits -- while the MFMA / DMA / LDS work and the M stores stay the same)"""
+    cin = cout = 544
+    T = 8 * 98 * 130
+    g = torch.Generator(device=DEV).manual_seed(0)
+    rows = -(-cout // 16) * 16
+    V3 = torch.randn(3, 36, cin // 32, T, 32, device=DEV, generator=g, dtype=torch.float32).to(torch.bfloat16)
+    U3 = (torch.randn(3, 36, cin // 32, rows, 32, device=DEV, generator=g) / cin ** 0.5).to(torch.bfloat16)
+    Mw = torch.empty(36, T, cout, device=DEV)
+    print("\n| PF_S3_DBG | X operand | ms |")
+    print("|---|---|---|")
+    for d, nm in ((0, "every tile its own token rows (full kernel)"), (16, "every tile the rows of token tile 0 (L2-resident)"), (0, "full kernel again")):
+        os.environ["PF_S3_DBG"] = str(d)
+        t = ops.gemm_planes_split3(V3, U3, Mw, T, cin, cout, 5)
+        print(f"| {d} | {nm} | {t:.3f} |")
+    os.environ.pop("PF_S3_DBG", None)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["wino", "vit"]
     if "wino" in what:
@@ -189,3 +256,7 @@ if __name__ == "__main__":
         decomp()
     if "layers" in what:
         layers()
+    if "traffic" in what:
+        traffic()
+    if "t192sweep" in what:
+        t192sweep()

@@ -299,7 +299,7 @@ def roofline(dtype, dev, gemm_only=False):
     if (pw.wino_u3 is not None and pk.winograd_applies(pw, B * H * W, 1, 1, "relu") and hip_ops._split3_three_step(pw) and
             not hip_ops._fused_wanted(B, H, W, pw)):
         # round 3 (late): the layer runs as input transform (three bf16 planes) -> ONE batched split-precision GEMM launch over the 36 transform
-        # points -> output transform.  Dominant launch = that GEMM (gemm_split3_kernel, v_mfma_f32_16x16x32_bf16 x 6 per useful product):
+        # points -> output transform.  Dominant launch = that GEMM (round 4: gemm_split3_persist192_kernel, v_mfma_f32_16x16x32_bf16 x 6 per useful product):
         # priced as its USEFUL float32 multiply-adds 36 * 2 * T * C * C against the f32 MFMA peak -- the roofline of the arithmetic the layer
         # asks for -- with the executed bf16 rate against the bf16 peak beside it.
         T = B * -(-H // 4) * -(-W // 4)
@@ -325,7 +325,7 @@ def roofline(dtype, dev, gemm_only=False):
         # touches, printed 0.96 for a launch whose matrix pipe was 48 % busy)
         peak = PEAK_TFLOPS["bf16"] / 6.0
         return {"bound": "mfma",
-                "kernel": f"gemm_split3_persist_kernel (6 x v_mfma_f32_16x16x32_bf16 per float32 product, f32 accumulation) as the batched transform-domain GEMM of the "
+                "kernel": f"gemm_split3_persist192_kernel (persistent 192 x 192 tiles, 6 x v_mfma_f32_16x16x32_bf16 per float32 product, f32 accumulation) as the batched transform-domain GEMM of the "
                           f"largest layer: 36 planes x [{T} x {C}].[{C} x {C}] = 3x3 {C}->{C} @ {B}x{H}x{W} (GuidedFusion up-conv) under Winograd F(4x4,3x3)",
                 "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "traffic": traffic, "winograd_m": 4,

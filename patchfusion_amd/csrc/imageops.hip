@@ -819,6 +819,7 @@ static bool resize_v2() {
 
 // grid of the source-aligned kernels: x = up to 4 blocks per source row, y = groups of rpb consecutive source rows of one image;
 // LDS = row ranges [8] + column ranges [Wmax] + weights [OW]
+constexpr int PF_RESIZE_V1 = -1;      // launch_resize_src: the source-aligned kernel's tables do not fit (W + OW above ~7.4k) -> use the v1 kernel
 template <typename T>
 static int launch_resize_src(const ResizeSrc* s, int nsrc, int B, void* y, int y_ld, int OH, int OW, const void* add, int add_ld, hipStream_t st) {
   constexpr int N = 16 / sizeof(T);
@@ -831,7 +832,7 @@ static int launch_resize_src(const ResizeSrc* s, int nsrc, int B, void* y, int y
     items = it > items ? it : items;
   }
   const size_t lds = RESIZE_RPB * 8 + (size_t)Wmax * 8 + (size_t)OW * 8;
-  if (items >= (1L << 22) || lds > 60000) return PF_ERR_ARG;
+  if (items >= (1L << 22) || lds > 60000) return PF_RESIZE_V1;       // (very wide maps: the caller falls through to the output-walking kernels)
   // rows per block: 8 when that still leaves >= 4 blocks per CU, fewer for small maps
   const long gx = (items + 255) / 256 > 4 ? 4 : (items + 255) / 256;
   int rpb = RESIZE_RPB;
@@ -850,8 +851,9 @@ extern "C" int pf_resize_bilinear(const void* x, int x_ld, int B, int H, int W, 
   const bool homogeneous = dtype == PF_DTYPE_BF16 ? (!in_f32 && !out_f32) : true;      // (dtype f32: everything is float32)
   if (homogeneous && resize_v2()) {
     const ResizeSrc s0{x, x_ld, H, W, C, ac_scale(H, OH), ac_scale(W, OW)};
-    return dtype == PF_DTYPE_BF16 ? launch_resize_src<bf16_t>(&s0, 1, B, y, y_ld, OH, OW, add, add_ld, ST(stream))
-                                  : launch_resize_src<float>(&s0, 1, B, y, y_ld, OH, OW, add, add_ld, ST(stream));
+    const int rc = dtype == PF_DTYPE_BF16 ? launch_resize_src<bf16_t>(&s0, 1, B, y, y_ld, OH, OW, add, add_ld, ST(stream))
+                                          : launch_resize_src<float>(&s0, 1, B, y, y_ld, OH, OW, add, add_ld, ST(stream));
+    if (rc != PF_RESIZE_V1) return rc;
   }
   LAUNCH_ROWS(resize_bilinear_kernel, B * OH, OW * (C / 8), x, x_ld, B, H, W, C, y, y_ld, OH, OW, add, add_ld, in_f32, out_f32,
               ac_scale(H, OH), ac_scale(W, OW));
@@ -871,9 +873,11 @@ extern "C" int pf_resize_concat(const void* const* xs, const int* lds, const int
   int cvmax = 0;
   for (int i = 0; i < nsrc; ++i) cvmax = Cs[i] / 8 > cvmax ? Cs[i] / 8 : cvmax;
   (void)cv;
-  if (resize_v2())
-    return dtype == PF_DTYPE_BF16 ? launch_resize_src<bf16_t>(s, nsrc, B, y, y_ld, OH, OW, nullptr, 0, ST(stream))
-                                  : launch_resize_src<float>(s, nsrc, B, y, y_ld, OH, OW, nullptr, 0, ST(stream));
+  if (resize_v2()) {
+    const int rc = dtype == PF_DTYPE_BF16 ? launch_resize_src<bf16_t>(s, nsrc, B, y, y_ld, OH, OW, nullptr, 0, ST(stream))
+                                          : launch_resize_src<float>(s, nsrc, B, y, y_ld, OH, OW, nullptr, 0, ST(stream));
+    if (rc != PF_RESIZE_V1) return rc;
+  }
   LAUNCH_ROWS(resize_concat_kernel, B * OH, OW * cvmax, s[0], s[1], s[2], nsrc, B, y, y_ld, OH, OW);
   return ok();
 }

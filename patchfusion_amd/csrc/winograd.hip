@@ -233,7 +233,7 @@ int run(const pf_conv_params* p, const float* U, int u_rows, int u_kpad, float* 
 }
 
 // F(4x4,3x3) with the transform-domain GEMM in split precision: V is written as three bf16 planes, U3 = the three planes of G g G^T
-// ([3][36][u_rows][u_kpad] bf16, packing.winograd_filters_split3), ONE batched pf_gemm_split3 launch (plane = blockIdx.y), M float32.
+// (chunk-major [3][36][Cin/32][u_rows][32] bf16 = PackedConv.wino_u3, the split3 of packing.winograd_filters), ONE batched pf_gemm_split3 launch (plane = blockIdx.y), M float32.
 int run_split3(const pf_conv_params* p, const void* U3, int u_rows, int u_kpad, void* V3, float* M, hipStream_t st) {
   constexpr int MT = 4, A = 6;
   const int TH = (p->H + MT - 1) / MT, TW = (p->W + MT - 1) / MT;

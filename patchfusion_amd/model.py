@@ -181,6 +181,18 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
         external_core = getattr(self.config[prefix[:-1]], "type", None) == 'ZoeDepth'
         unexpected = [k for k in branch_sd if k not in wanted and not (external_core and k.startswith("core."))]
         if external_core:
+            # the core's own weights go to the injected provider, strictly, when it can take them (an nn.Module-like provider); a checkpoint that
+            # carries `core.` keys with no provider to receive them is reported -- the keys are not silently dropped (round-3 advisor finding)
+            core_sd = {k[len("core."):]: v for k, v in branch_sd.items() if k.startswith("core.") and k not in wanted}
+            if core_sd:
+                provider = self.core_providers[0 if prefix.startswith("coarse") else 1]
+                if provider is not None and hasattr(provider, "load_state_dict"):
+                    provider.load_state_dict(core_sd, strict=True)
+                else:
+                    import warnings
+                    warnings.warn(f"{prefix[:-1]}: {len(core_sd)} checkpoint tensors under 'core.' belong to the external MiDaS/BEiT core; "
+                                  f"{'the injected provider has no load_state_dict' if provider is not None else 'no core provider is set'} "
+                                  "-- they are NOT loaded (set_core_providers / core_providers=...)", stacklevel=2)
             branch_sd = {k: v for k, v in branch_sd.items() if k in wanted}
         if missing or unexpected:
             raise RuntimeError(f"Error(s) in loading state_dict for {prefix[:-1]}: Missing key(s): {missing[:8]}"

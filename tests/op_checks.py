@@ -131,13 +131,19 @@ def conv_winograd_fused(dt):
                 (3, 5, 29, 128, 96, 1, dict(act="relu", res=True)),
                 (8, 56, 74, 768, 256, 8, dict(act="relu")),
                 (1, 392, 518, 128, 32, 8, dict(act="relu")),
-                (2, 112, 148, 256, 256, 5, dict(relu_in=True, act="relu", res=True)))):
+                (2, 112, 148, 256, 256, 5, dict(relu_in=True, act="relu", res=True)),
+                # fused-ONLY layers (32 <= Cin < 128 or Cout % 32 != 0: no three-step form, PF_WINO_FUSED=0 runs the direct kernel): odd
+                # chunk-pair DMA tails (Cin / 8 odd pairs), partial channel quads in the epilogue, partial tiles
+                (1, 37, 45, 48, 64, 8, dict(act="relu")),
+                (8, 98, 129, 64, 32, 8, dict(act="relu")),
+                (1, 21, 33, 80, 36, 4, dict(res=True)),
+                (2, 17, 23, 32, 4, 8, dict(act="relu", relu_in=True)))):
             os.environ["PF_WINO_GS"] = str(gs)
             _switches_changed()
             g = torch.Generator().manual_seed(100 + i)
             w = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
             pw = pk.pack_conv(w, torch.randn(cout, generator=g), dtype=torch.float32).to(DEV)
-            assert pw.wino_m == 4 and pw.wino_up is not None
+            assert pw.wino_m == 4 and pw.wino_up is not None and (pw.wino_u is None) == (cin < 128 or cout % 32 != 0)
             xb = _rand((B, H, W, cin + 16), torch.float32, 200 + i)
             x = xb[..., 8:8 + cin]
             r1 = _rand((B, H, W, cout), torch.float32, 300 + i) if kw.get("res") else None
@@ -647,7 +653,8 @@ def swin_ops(dt):
 
 def resize_ops(dt):
     errs = []
-    for (h, w, oh, ow, C) in ((14, 19, 28, 37, 64), (49, 64, 56, 74, 32), (224, 296, 392, 518, 8), (12, 16, 14, 19, 128), (8, 11, 8, 11, 64)):
+    # (the last case: W + OW above the ~7.4k the source-aligned kernel's LDS tables hold -> the library falls through to the output-walking kernel)
+    for (h, w, oh, ow, C) in ((14, 19, 28, 37, 64), (49, 64, 56, 74, 32), (224, 296, 392, 518, 8), (12, 16, 14, 19, 128), (8, 11, 8, 11, 64), (2, 4000, 3, 4100, 8)):
         x = _rand((2, h, w, C), dt, h)
         add = _rand((2, oh, ow, C), dt, w)
         res = []

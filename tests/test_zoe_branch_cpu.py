@@ -122,8 +122,21 @@ def test_zoe_branch_checkpoint_with_core_weights_loads_through_the_configdict_ro
 
     c = ConfigDict(cfg)
     c["pretrain_model"] = paths
-    m = PatchFusion(c, ops=fake_ops, core_providers=(StandInCore(11), StandInCore(12)))
+    with pytest.warns(UserWarning, match="NOT loaded"):       # the stand-in cores cannot take weights: said aloud, not dropped silently
+        m = PatchFusion(c, ops=fake_ops, core_providers=(StandInCore(11), StandInCore(12)))
     assert m.config.load_branch is True
+
+    class TakingCore(StandInCore):       # a provider that owns its weights receives the `core.` sub-dict, strictly
+        def load_state_dict(self, sd, strict=True):
+            assert strict and sorted(sd) == ["core.pretrained.model.blocks.0.attn.qkv.weight", "core.scratch.refinenet1.out_conv.bias"]
+            self.loaded = dict(sd)
+
+    taking = (TakingCore(11), TakingCore(12))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        PatchFusion(c, ops=fake_ops, core_providers=taking)
+    assert all(len(t.loaded) == 2 for t in taking)
     got = m.state_dict()
     assert all(torch.equal(got[k], v) for k, v in sd.items() if k.startswith(("coarse_branch.", "fine_branch.")))
     # an unknown non-core key is still an error, like load_state_dict(strict=True)

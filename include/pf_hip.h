@@ -100,7 +100,10 @@ int pf_conv_winograd_fused_timed(const pf_conv_params* p, const void* up, int nn
  * (value 4) = every w plane is chunk-major [Cin/32][w_rows][32] (Kpad must equal Cin): each 32-deep K chunk of all rows is one contiguous
  * slab, which is what the kernel's 1-KiB LDS-DMA pieces want (whole cache lines); bit 3 (value 8) = the three-plane OUTPUT (out_f32 == 0) is
  * written chunk-major [Cout/32][M][32] (y_ld must equal Cout, Cout % 32 == 0) for a following split GEMM.  p->batch > 1: that many independent planes in one launch
- * (block k of every x / w plane, float32 output block k, no epilogue) -- the transform points of pf_conv_winograd_split3. */
+ * (block k of every x / w plane, float32 output block k, no epilogue) -- the transform points of pf_conv_winograd_split3.
+ * Kernel choice is internal and result-identical (same chunk order, same six terms per accumulator): 64 x 128 tiles below one round of tiles,
+ * one 128 x 128 tile per block, or -- from two rounds of tiles on -- a PERSISTENT kernel (one block per CU walks its tiles) with 128 x 128 tiles
+ * on a three-slot LDS ring or 192 x 192 tiles on a two-slot ring, whichever costs fewer rounds x tile cost. */
 int pf_gemm_split3(const pf_conv_params* p, void* stream);
 int pf_gemm_split3_timed(const pf_conv_params* p, int iters, float* ms, void* stream);
 /* A plain bf16 linear layer (x [M][x_ld] bf16, w from packing.pack_conv, bf16 residuals / output, float32 output when out_f32) through the same

@@ -105,6 +105,12 @@ int pf_conv_winograd_fused_timed(const pf_conv_params* p, const void* up, int nn
  * one 128 x 128 tile per block, or -- from two rounds of tiles on -- a PERSISTENT kernel (one block per CU walks its tiles) with 128 x 128 tiles
  * on a three-slot LDS ring or 192 x 192 tiles on a two-slot ring, whichever costs fewer rounds x tile cost. */
 int pf_gemm_split3(const pf_conv_params* p, void* stream);
+/* which of those kernels a call would run on a chip of `cus` compute units (no launch, no GPU needed: the dispatch rule for host-side tests) */
+#define PF_S3_ROUTE_TILE64 0
+#define PF_S3_ROUTE_TILE128 1
+#define PF_S3_ROUTE_PERSIST128 2
+#define PF_S3_ROUTE_PERSIST192 3
+int pf_gemm_split3_route(const pf_conv_params* p, int cus);
 int pf_gemm_split3_timed(const pf_conv_params* p, int iters, float* ms, void* stream);
 /* A plain bf16 linear layer (x [M][x_ld] bf16, w from packing.pack_conv, bf16 residuals / output, float32 output when out_f32) through the same
  * ping-pong LDS-DMA pipeline: 256 x 128 tiles, Cin % 64 == 0.  The bf16 mode's ViT block linears at large token counts (same reference layers). */

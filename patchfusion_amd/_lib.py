@@ -83,7 +83,7 @@ SIGNATURES = {
     "pf_silog_loss": [vp, vp, cl, cf, cf, cf, vp, vp, vp],
     "pf_depth_metrics": [vp, ci, ci, vp, ci, ci, vp, vp, cf, cf, ci, ci, ci, ci, vp, vp],
 }
-NON_STATUS = ("pf_last_error", "pf_version", "pf_percentile_workspace_bytes", "pf_conv_winograd_fused_supported")   # entry points that do not return a status
+NON_STATUS = ("pf_last_error", "pf_version", "pf_percentile_workspace_bytes", "pf_conv_winograd_fused_supported", "pf_gemm_split3_route")   # entry points that do not return a status
 
 _lib = None
 
@@ -110,6 +110,8 @@ def load():
     lib.pf_percentile_workspace_bytes.argtypes = []
     lib.pf_conv_winograd_fused_supported.restype = ci          # 1 / 0, not a status
     lib.pf_conv_winograd_fused_supported.argtypes = [C.POINTER(ConvParams)]
+    lib.pf_gemm_split3_route.restype = ci                      # PF_S3_ROUTE_* (or -1), not a status
+    lib.pf_gemm_split3_route.argtypes = [C.POINTER(ConvParams), ci]
     _lib = lib
     return lib
 

@@ -950,6 +950,41 @@ int launch(const pf_conv_params& p, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_LAUNCH;
 }
 
+// Which kernel runs a (validated) call on a chip of `cus` compute units -- the whole dispatch rule in one place (pf_gemm_split3_route exposes it to
+// the CPU tests).  The PF_S3_* switches are A/B and test knobs, read per call.
+//   TILE64      64 x 128 tiles, two-slot ring (two blocks per CU): the token x channel grid does not fill the chip once with 128 x 128 tiles
+//   TILE128     one 128 x 128 tile per block, ping-pong (profiles/r3_split3_pingpong.log: wins from one full round of tiles on)
+//   PERSIST128  from two rounds of tiles on: one resident block per CU walks its tiles, chunk stream continuous across tiles (round 4)
+//   PERSIST192  the same walk over 192 x 192 tiles on a two-slot ring when that costs less: rounds of tiles per CU x cost of a tile, a 192-tile
+//               being 2.25x the products of a 128-tile run ~8 % faster (profiles/r4_t192_sweep.md: 768->768 1.06x, exact in both tilings) = 2.1.
+//               N = 544 pads to 576 instead of 640 columns (1.15x), 768 / 3072 / 4096 gain 1.05-1.12x; N <= 256 and the 8296 x 1024
+//               projections (264 tiles on 256 CUs) stay on 128 x 128.  PF_S3_T192: 0 = never, 2 = wherever legal.
+int split3_route(const pf_conv_params& p, int cus) {
+  int force = 0;
+  if (const char* s = getenv("PF_S3_TILE_NOW")) force = atoi(s);
+  const long M = (long)p.B * p.OH * p.OW;
+  const long t128 = ((M + 127) / 128) * ((p.Cout + 127) / 128);
+  if (force ? force == 64 : t128 < 256) return PF_S3_ROUTE_TILE64;
+  const char* ps = getenv("PF_S3_PERSIST");
+  const long planes = p.batch > 1 ? p.batch : 1;
+  if (!(ps && ps[0] == '0') && p.Cin >= 96 && (t128 * planes >= 2L * cus || (ps && ps[0] == '2')) && t128 * planes >= 8) {
+    const char* ts = getenv("PF_S3_T192");
+    const long t192 = ((M + 191) / 192) * ((p.Cout + 191) / 192);
+    const long cost128 = ((t128 * planes + cus - 1) / cus) * 100, cost192 = ((t192 * planes + cus - 1) / cus) * 210;
+    const bool want = ts && ts[0] == '2' ? true : (ts && ts[0] == '0' ? false : cost192 < cost128);
+    return want && t192 * planes >= 8 ? PF_S3_ROUTE_PERSIST192 : PF_S3_ROUTE_PERSIST128;
+  }
+  return PF_S3_ROUTE_TILE128;
+}
+
+}  // namespace
+
+extern "C" int pf_gemm_split3_route(const pf_conv_params* p, int cus) {
+  if (!p || cus <= 0) return -1;
+  return split3_route(*p, cus);
+}
+
+namespace {
 }  // namespace
 
 extern "C" int pf_gemm_split3(const pf_conv_params* p, void* stream) {
@@ -978,28 +1013,11 @@ extern "C" int pf_gemm_split3(const pf_conv_params* p, void* stream) {
 #endif
   if (e) return PF_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  // tile: 128 x 128 (eight waves, one block per CU, ping-pong) unless the token x channel grid does not fill the chip once; PF_S3_TILE_NOW forces
-  int force = 0;
-  if (const char* s = getenv("PF_S3_TILE_NOW")) force = atoi(s);      // (tests: read per call)
-  const long M = (long)p->B * p->OH * p->OW;
-  const long t128 = ((M + 127) / 128) * ((p->Cout + 127) / 128);
-  const bool small = force ? force == 64 : t128 < 256;       // (ping-pong 128 x 128 wins from one full round of tiles on: profiles/r3_split3_pingpong.log)
-    if (small) return launch<64, 128, 2, 2, 2>(*p, st);
-  // from two full rounds of tiles on: the persistent tile walk (one block per CU, chunk stream continuous across tiles); PF_S3_PERSIST=0 = A/B
-  const char* ps = getenv("PF_S3_PERSIST");
-  const long planes = p->batch > 1 ? p->batch : 1;
-  if (!(ps && ps[0] == '0') && p->Cin >= 96 && (t128 * planes >= 2L * cu_count() || (ps && ps[0] == '2')) && t128 * planes >= 8) {
-    // 192 x 192 tiles or 128 x 128?  PF_S3_T192: 0 = never, 2 = wherever legal, default = the cheaper by rounds of tiles per CU x cost of a tile:
-    // a 192-tile is 2.25x the products of a 128-tile and runs them ~8 % faster (profiles/r4_t192_sweep.md: 768->768 1.06x, exact in both
-    // tilings), i.e. costs 2.1 -- N = 544 pads to 576 instead of 640 columns (1.15x), 768 / 3072 / 4096 gain 1.05-1.12x, while N <= 256 and
-    // the 8296 x 1024 projections (264 tiles on 256 CUs) stay on 128 x 128
-    const char* ts = getenv("PF_S3_T192");
-    const long t192 = ((M + 191) / 192) * ((p->Cout + 191) / 192);
-    const long cus = cu_count();
-    const long cost128 = ((t128 * planes + cus - 1) / cus) * 100, cost192 = ((t192 * planes + cus - 1) / cus) * 210;
-    const bool want = ts && ts[0] == '2' ? true : (ts && ts[0] == '0' ? false : cost192 < cost128);
-    if (want && t192 * planes >= 8) return launch_persist192(*p, st);
-    return launch_persist(*p, st);
+  switch (split3_route(*p, cu_count())) {
+    case PF_S3_ROUTE_TILE64: return launch<64, 128, 2, 2, 2>(*p, st);
+    case PF_S3_ROUTE_PERSIST192: return launch_persist192(*p, st);
+    case PF_S3_ROUTE_PERSIST128: return launch_persist(*p, st);
+    default: break;
   }
   const char* pp = getenv("PF_S3_PP");                    // (A/B switch; read per call)
   return (pp && pp[0] == '0') ? launch<128, 128, 4, 2, 3, false>(*p, st) : launch<128, 128, 4, 2, 3, true>(*p, st);

@@ -59,3 +59,40 @@ def test_fused_versus_three_step_rule(monkeypatch):
     assert not fw(8, 392, 518, p544) and not fw(8, 392, 518, p64_32)
     monkeypatch.setenv("PF_WINO_FUSED", "2")
     assert fw(1, 28, 37, p768)
+
+
+def test_split_gemm_kernel_choice_by_shape(monkeypatch):
+    """pf_gemm_split3_route (csrc/gemm_split3.hip split3_route, no launch, no GPU): which of the four split-GEMM kernels a call runs on a 256-CU chip --
+    the launches of the 4K ViT-L pass named in DESIGN.md 4g.  Round 4's rule: persistent from two rounds of 128 x 128 tiles on, 192 x 192 tiles when
+    rounds of tiles per CU x tile cost (2.1 vs 1.0) is lower."""
+    import ctypes as C
+    try:
+        from patchfusion_amd import _lib
+        L = _lib.load()
+    except Exception as e:
+        pytest.skip(f"libpf_hip.so not built: {e}")
+    for v in ("PF_S3_TILE_NOW", "PF_S3_PERSIST", "PF_S3_T192", "PF_S3_GRID"):
+        monkeypatch.delenv(v, raising=False)
+    T64, T128, P128, P192 = 0, 1, 2, 3
+
+    def route(M, K, N, planes=1, cus=256):
+        p = _lib.ConvParams()
+        p.B, p.OH, p.OW, p.H, p.W, p.Cin, p.Cout, p.batch = 1, 1, M, 1, M, K, N, planes
+        return L.pf_gemm_split3_route(C.byref(p), cus)
+
+    T = 8 * 98 * 130
+    assert route(T, 544, 544, 36) == P192                        # the dominant launch: 576 instead of 640 columns
+    assert route(8 * 56 * 74, 768, 768, 36) == P192              # 768 = 4 x 192 = 6 x 128: the faster tile
+    assert route(8 * 56 * 74, 768, 256, 36) == P128              # 256 would pad to 384
+    assert route(8 * 56 * 74, 256, 256, 36) == P128
+    assert route(8 * 1037, 1024, 3072) == P192 and route(8 * 1037, 1024, 4096) == P192        # qkv, fc1
+    assert route(8 * 1037, 1024, 1024) == P128 and route(8 * 1037, 4096, 1024) == P128        # proj, fc2: 264 192-tiles on 256 CUs = two rounds
+    assert route(1037, 1024, 4096) == T128 and route(1037, 1024, 1024) == T64                 # the coarse branch: one round of tiles or less
+    assert route(8 * 1037, 64, 3072) == T128                     # K below three chunks: no stream to keep going
+    monkeypatch.setenv("PF_S3_T192", "0")
+    assert route(T, 544, 544, 36) == P128
+    monkeypatch.setenv("PF_S3_T192", "2")
+    assert route(8 * 1037, 1024, 1024) == P192
+    monkeypatch.setenv("PF_S3_PERSIST", "0")
+    assert route(T, 544, 544, 36) == T128
+    assert L.pf_gemm_split3_route(None, 256) == -1

@@ -365,6 +365,12 @@ __global__ __launch_bounds__(512) void gemm_split3_persist_kernel(const pf_conv_
   auto decode = [&](int l, int& z, int& m0, int& n0) __attribute__((always_inline)) {
     z = l / per_plane;
     const int r = l - z * per_plane;
+    if (gm == 0) {                                        // channel tile fastest (tile_group: nt does not divide an XCD's 32 blocks)
+      const int t = r / nt;
+      m0 = t * BM;
+      n0 = (r - t * nt) * BN;
+      return;
+    }
     const int group = r / per_group, in_g = r - group * per_group, first = group * gm;
     const int gsz = min(mt - first, gm);
     const int tn = in_g / gsz;
@@ -639,6 +645,12 @@ __global__ __launch_bounds__(512) void gemm_split3_persist192_kernel(const pf_co
   auto decode = [&](int l, int& z, int& m0, int& n0) __attribute__((always_inline)) {
     z = l / per_plane;
     const int r = l - z * per_plane;
+    if (gm == 0) {                                        // channel tile fastest (tile_group: nt does not divide an XCD's 32 blocks)
+      const int t = r / nt;
+      m0 = t * BM;
+      n0 = (r - t * nt) * BN;
+      return;
+    }
     const int group = r / per_group, in_g = r - group * per_group, first = group * gm;
     const int gsz = min(mt - first, gm);
     const int tn = in_g / gsz;
@@ -874,6 +886,19 @@ int cu_count() {
   return c;
 }
 
+// Tile order of the persistent kernels inside a transform point: the ~32 tiles an XCD works on at once are consecutive in the order, and they
+// should be a patch whose X and W panels are shared through that XCD's L2.  nt (channel tiles) dividing 32: gm = 32 / nt token tiles x all channel
+// tiles, column by column; nt > 6: 8 token tiles x 4 channel tiles.  nt = 3, 5, 6 (30-tile patches): a third of the blocks that share an X panel
+// would fall into DIFFERENT iterations of the 32-block XCD (46 us apart: an L2 miss each) -- those run channel-tile-fastest instead (returned as
+// gm = 0): the nt sharers of a token tile are adjacent in the order, all W panels (nt x 209 KB at K = 544) stay hot.  PF_S3_ORDER=0: the patches.
+int tile_group(int nt) {
+  if (nt == 3 || nt == 5 || nt == 6) {
+    const char* s = getenv("PF_S3_ORDER");
+    if (!(s && s[0] == '0')) return 0;
+  }
+  return nt <= 6 ? 32 / nt : 8;
+}
+
 // persistent launch: 128 x 128 tiles, one block per CU (grid = a multiple of 8 so that every XCD has blocks)
 int launch_persist(const pf_conv_params& p, hipStream_t st) {
   constexpr int smem = 3 * 3 * (128 + 128) * 64;
@@ -889,7 +914,7 @@ int launch_persist(const pf_conv_params& p, hipStream_t st) {
   const long M = (long)p.B * p.OH * p.OW;
   const int mt = (int)((M + 127) / 128), nt = (p.Cout + 127) / 128;
   const long total = (long)mt * nt * (p.batch > 1 ? p.batch : 1);
-  const int gm = nt <= 6 ? 32 / nt : 8;
+  const int gm = tile_group(nt);
   int grid = cu_count();
   if (const char* s = getenv("PF_S3_GRID")) grid = atoi(s);              // (tests: fewer blocks than CUs = more tiles per block; read per call)
   if (grid > total) grid = (int)total;
@@ -920,7 +945,7 @@ int launch_persist192(const pf_conv_params& p, hipStream_t st) {
   const long M = (long)p.B * p.OH * p.OW;
   const int mt = (int)((M + 191) / 192), nt = (p.Cout + 191) / 192;
   const long total = (long)mt * nt * (p.batch > 1 ? p.batch : 1);
-  const int gm = nt <= 6 ? 32 / nt : 8;
+  const int gm = tile_group(nt);
   int grid = cu_count();
   if (const char* s = getenv("PF_S3_GRID")) grid = atoi(s);              // (tests: fewer blocks than CUs = more tiles per block; read per call)
   if (grid > total) grid = (int)total;
@@ -956,7 +981,8 @@ int launch(const pf_conv_params& p, hipStream_t st) {
 //   TILE128     one 128 x 128 tile per block, ping-pong (profiles/r3_split3_pingpong.log: wins from one full round of tiles on)
 //   PERSIST128  from two rounds of tiles on: one resident block per CU walks its tiles, chunk stream continuous across tiles (round 4)
 //   PERSIST192  the same walk over 192 x 192 tiles on a two-slot ring when that costs less: rounds of tiles per CU x cost of a tile, a 192-tile
-//               being 2.25x the products of a 128-tile run ~8 % faster (profiles/r4_t192_sweep.md: 768->768 1.06x, exact in both tilings) = 2.1.
+//               being 2.25x the products of a 128-tile run ~8 % faster (profiles/r4_t192_sweep.md: 768->768 1.06x, exact in both tilings) = 2.1,
+//               plus half a round for the coarser tail (768->768 @ 8x56x74, 7 rounds of 192-tiles: 0.455 ms against 0.415 on 15 rounds of 128-tiles).
 //               N = 544 pads to 576 instead of 640 columns (1.15x), 768 / 3072 / 4096 gain 1.05-1.12x; N <= 256 and the 8296 x 1024
 //               projections (264 tiles on 256 CUs) stay on 128 x 128.  PF_S3_T192: 0 = never, 2 = wherever legal.
 int split3_route(const pf_conv_params& p, int cus) {
@@ -964,13 +990,15 @@ int split3_route(const pf_conv_params& p, int cus) {
   if (const char* s = getenv("PF_S3_TILE_NOW")) force = atoi(s);
   const long M = (long)p.B * p.OH * p.OW;
   const long t128 = ((M + 127) / 128) * ((p.Cout + 127) / 128);
-  if (force ? force == 64 : t128 < 256) return PF_S3_ROUTE_TILE64;
-  const char* ps = getenv("PF_S3_PERSIST");
   const long planes = p.batch > 1 ? p.batch : 1;
+  // (tiles of ALL planes: the 36 transform points of a small Winograd layer -- 768->768 @ 8x56x74 is 102 tiles per point, 3672 in the launch --
+  // used to count per plane and fell to the 64 x 128 kernel: 0.51 ms against 0.40 through the persistent walk)
+  if (force ? force == 64 : t128 * planes < 256) return PF_S3_ROUTE_TILE64;
+  const char* ps = getenv("PF_S3_PERSIST");
   if (!(ps && ps[0] == '0') && p.Cin >= 96 && (t128 * planes >= 2L * cus || (ps && ps[0] == '2')) && t128 * planes >= 8) {
     const char* ts = getenv("PF_S3_T192");
     const long t192 = ((M + 191) / 192) * ((p.Cout + 191) / 192);
-    const long cost128 = ((t128 * planes + cus - 1) / cus) * 100, cost192 = ((t192 * planes + cus - 1) / cus) * 210;
+    const long cost128 = ((t128 * planes + cus - 1) / cus) * 100, cost192 = ((t192 * planes + cus - 1) / cus) * 210 + 50;   // (+ half a round: coarser tail)
     const bool want = ts && ts[0] == '2' ? true : (ts && ts[0] == '0' ? false : cost192 < cost128);
     return want && t192 * planes >= 8 ? PF_S3_ROUTE_PERSIST192 : PF_S3_ROUTE_PERSIST128;
   }

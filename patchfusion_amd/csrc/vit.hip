@@ -736,7 +736,10 @@ __global__ __launch_bounds__(256, QG == 1 ? 3 : 2) void vit_attention_qkv_f32_ke
 //   Ks[p][key][64 d]   bf16, 128-byte rows, 16-byte slot s of row key at slot s ^ (key & 7)
 //   Vs[p][d][64 keys]  bf16, transposed while staging; inside each 32-key block key 16 a + 4 g + t sits at position 8 g + 4 a + t, so that
 //                      the eight keys a lane holds of P (two accumulator quads: keys 4 g + t of two 16-key fragments) are ONE 16-byte read
-//                      of V^T; 16-byte slot s of row d at slot s ^ (d & 7)
+//                      of V^T; 16-byte slot s of row d at slot s ^ (d & 7) ^ (((d >> 4) & 3) << 1).  (The second term is round 4: the transposing
+//                      4-byte stores of a 32-lane group go to rows d = 8 slot + e, slot = 0..7 -- without it all eight hit ONE bank (PMC: 54 % of the
+//                      kernel's LDS cycles were bank conflicts); with it four banks, two lanes each, which a ds_write_b32 absorbs.  For the fragment
+//                      reads, d = 16 fd + r, it is a per-instruction constant: they stay conflict-free.)
 // S^T fragment kf (16 keys): A = K rows (lane (r = key, g): d = 32 kh + 8 g ..), B = Q (lane (r = query, g): same d) -> lane (query r, g)
 // holds keys 16 kf + 4 g + e.  O^T fragment df (16 d): A = V^T rows (lane (r = d, g): the eight permuted keys of block kk), B = P.
 // ---------------------------------------------------------------------------------------------------------------------------------------
@@ -831,9 +834,9 @@ __global__ __launch_bounds__(256, 3) void vit_attention_split3_kernel(const bf16
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int d = 8 * slot + e;
-        const uint32_t lo = (e & 1) ? (w0[e >> 1] >> 16) : (w0[e >> 1] & 0xffffu);
-        const uint32_t hi = (e & 1) ? (w1[e >> 1] >> 16) : (w1[e >> 1] & 0xffffu);
-        *reinterpret_cast<uint32_t*>(Vs + (pl * 64 + d) * 128 + (((pos >> 3) ^ (d & 7)) << 4) + (pos & 7) * 2) = lo | (hi << 16);
+        // (key 2 j, key 2 j + 1) of channel d as one dword: v_perm_b32 picks the two low (even e) / high (odd e) halves in ONE instruction
+        const uint32_t pair = __builtin_amdgcn_perm(w1[e >> 1], w0[e >> 1], (e & 1) ? 0x07060302u : 0x05040100u);
+        *reinterpret_cast<uint32_t*>(Vs + (pl * 64 + d) * 128 + (((pos >> 3) ^ (d & 7) ^ (((d >> 4) & 3) << 1)) << 4) + (pos & 7) * 2) = pair;
       }
     }
   };
@@ -869,14 +872,14 @@ __global__ __launch_bounds__(256, 3) void vit_attention_split3_kernel(const bf16
     for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float v = sacc[kf][e] * qscale;
+        float v = sacc[kf][e];                 // raw q.k: the positive scale commutes with the max and is folded into the exponent's FMA below
         if (last && kt * 64 + 16 * kf + 4 * g + e >= S) v = -INFINITY;
         sacc[kf][e] = v;
         mx = fmaxf(mx, v);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
+    const float m_new = fmaxf(m_run, mx * qscale);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
     float psum = 0.f;
@@ -886,7 +889,7 @@ __global__ __launch_bounds__(256, 3) void vit_attention_split3_kernel(const bf16
       float pv[8];
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        pv[t] = __builtin_amdgcn_exp2f(sacc[2 * kk + (t >> 2)][t & 3] - m_new);
+        pv[t] = __builtin_amdgcn_exp2f(fmaf(sacc[2 * kk + (t >> 2)][t & 3], qscale, -m_new));
         psum += pv[t];
       }
       uint32_t hw[4], mw[4], lw[4];
@@ -906,7 +909,8 @@ __global__ __launch_bounds__(256, 3) void vit_attention_split3_kernel(const bf16
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) vfr[pl][kk] = *reinterpret_cast<const uint4*>(Vs + (pl * 64 + d) * 128 + (((4 * kk + g) ^ (d & 7)) << 4));
+        for (int kk = 0; kk < 2; ++kk)
+          vfr[pl][kk] = *reinterpret_cast<const uint4*>(Vs + (pl * 64 + d) * 128 + (((4 * kk + g) ^ (d & 7) ^ (((d >> 4) & 3) << 1)) << 4));
 #define AT_TERM(PV, PP)                                                                                                                   \
   _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) o[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                      \
       __builtin_bit_cast(bf16x8, vfr[PV][kk]), __builtin_bit_cast(bf16x8, pf[PP][kk]), o[fd], 0, 0, 0);

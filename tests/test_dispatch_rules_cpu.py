@@ -89,6 +89,7 @@ def test_split_gemm_kernel_choice_by_shape(monkeypatch):
     assert route(8 * 1037, 1024, 1024) == P128 and route(8 * 1037, 4096, 1024) == P128        # proj, fc2: 264 192-tiles on 256 CUs = two rounds
     assert route(1037, 1024, 4096) == T128 and route(1037, 1024, 1024) == T64                 # the coarse branch: one round of tiles or less
     assert route(8 * 1037, 64, 3072) == T128                     # K below three chunks: no stream to keep going
+    assert route(8 * 14 * 19, 768, 768, 36) == P128 and route(8 * 28 * 37, 768, 768, 36) == P192 and route(70, 768, 768, 36) == T64        # small Winograd layers count the tiles of all 36 points
     monkeypatch.setenv("PF_S3_T192", "0")
     assert route(T, 544, 544, 36) == P128
     monkeypatch.setenv("PF_S3_T192", "2")

@@ -360,7 +360,7 @@ def test_the_model_catches_an_early_issue_into_the_two_slot_ring():
 def _persist_tiles(mt, nt, planes, G):
     """host + device tile walk of gemm_split3_persist_kernel: returns, per block, the (z, tile_m, tile_n) it visits, in order"""
     total = mt * nt * planes
-    gm = 32 // nt if nt <= 6 else 8
+    gm = 0 if nt in (3, 5, 6) else (32 // nt if nt <= 6 else 8)       # csrc/gemm_split3.hip tile_group: 0 = channel tile fastest
     per_plane, per_group = mt * nt, gm * nt
     out = []
     for b in range(G):
@@ -370,18 +370,21 @@ def _persist_tiles(mt, nt, planes, G):
         l = lo + (b >> 3)
         while l < hi:
             z, r = divmod(l, per_plane)
-            group, in_g = divmod(r, per_group)
-            first = group * gm
-            gsz = min(mt - first, gm)
-            tn = in_g // gsz
-            seq.append((z, first + in_g - tn * gsz, tn))
+            if gm == 0:
+                seq.append((z, r // nt, r % nt))
+            else:
+                group, in_g = divmod(r, per_group)
+                first = group * gm
+                gsz = min(mt - first, gm)
+                tn = in_g // gsz
+                seq.append((z, first + in_g - tn * gsz, tn))
             l += nb
         out.append(seq)
     return out
 
 
 @pytest.mark.parametrize("mt,nt,planes,G", [(797, 5, 36, 256), (65, 24, 1, 256), (65, 8, 1, 256), (9, 5, 1, 16), (8, 2, 5, 40), (5, 2, 3, 8), (17, 1, 1, 8),
-                                            (259, 6, 36, 256), (65, 32, 1, 248), (3, 7, 2, 24)])
+                                            (259, 6, 36, 256), (65, 32, 1, 248), (3, 7, 2, 24), (531, 3, 36, 256), (44, 16, 1, 256)])
 def test_persistent_tile_walk_covers_every_tile_once(mt, nt, planes, G):
     walks = _persist_tiles(mt, nt, planes, G)
     seen = [t for w in walks for t in w]

@@ -175,12 +175,20 @@ def timeline():
     print("(s_memtime ticks = shader clock cycles; the instrumentation itself costs ~10 % of a chunk)")
 
 
+def ordersweep():
+    """tile order of the persistent kernels for nt = 3 / 5 / 6 channel tiles: channel tile fastest (default) against the 30-tile patches (PF_S3_ORDER=0)"""
+    _sweep((("PF_S3_ORDER",), ("0", "1")), only_wino=True)
+    os.environ["PF_S3_T192"] = "0"
+    _sweep((("PF_S3_ORDER",), ("0", "1")), only_wino=True)
+    os.environ.pop("PF_S3_T192")
+
+
 def t192sweep():
     """the 192 x 192 persistent kernel (two-slot ring, PF_S3_T192=2) against the 128 x 128 one (PF_S3_T192=0) on the same launches"""
     _sweep((("PF_S3_T192",), ("0", "2")))
 
 
-def _sweep(knob):
+def _sweep(knob, only_wino=False):
     names, p2s = knob
     print("| launch | " + " | ".join(f"{names[0]}={v} ms" for v in p2s) + " | best | useful TF/s at best | of 2500/6 |")
     print("|---|" + "---|" * (len(p2s) + 3))
@@ -207,6 +215,8 @@ def _sweep(knob):
         row(f"wino GEMM {cin}->{cout} @ {B}x{H}x{W}", 36 * 2.0 * T * cin * cout, lambda: ops.gemm_planes_split3(V3k, U3k, Mw, T, cin, cout, 5))
         del V3k, U3k, Mw
         torch.cuda.empty_cache()
+    if only_wino:
+        return
     gc = torch.Generator().manual_seed(0)
     os.environ["PF_S3_PERSIST"] = "2"
     for M in (8 * 1037, 1037):
@@ -258,5 +268,7 @@ if __name__ == "__main__":
         layers()
     if "traffic" in what:
         traffic()
+    if "ordersweep" in what:
+        ordersweep()
     if "t192sweep" in what:
         t192sweep()

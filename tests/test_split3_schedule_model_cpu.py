@@ -392,3 +392,40 @@ def test_persistent_tile_walk_covers_every_tile_once(mt, nt, planes, G):
     assert all(0 <= z < planes and 0 <= m < mt and 0 <= n < nt for z, m, n in seen)
     lens = [len(w) for w in walks]
     assert max(lens) - min(lens) <= 1 + (1 if (mt * nt * planes) % 8 else 0), lens     # balanced to within a tile (plus the XCD range rounding)
+
+
+def _split_sharers(mt, nt, planes, G, order):
+    """fraction of (token tile, plane) X panels whose nt channel tiles are NOT all taken in the same iteration of their XCD's blocks, for the two
+    tile orders of the persistent kernels: 'patch' = gm x nt patches column by column (gm = 32 // nt), 'channel' = channel tile fastest"""
+    total = mt * nt * planes
+    per_plane = mt * nt
+    split = panels = 0
+    for xcd in range(8):
+        nb = (G - xcd + 7) >> 3
+        lo, hi = total * xcd // 8, total * (xcd + 1) // 8
+        it_of = {}
+        for l in range(lo, hi):
+            z, r = divmod(l, per_plane)
+            if order == "channel":
+                t = r // nt
+            else:
+                gm = 32 // nt
+                group, in_g = divmod(r, gm * nt)
+                first = group * gm
+                gsz = min(mt - first, gm)
+                t = first + in_g % gsz
+            it_of.setdefault((z, t), set()).add((l - lo) // nb)
+        for its in it_of.values():
+            panels += 1
+            split += len(its) > 1
+    return split / panels
+
+
+@pytest.mark.parametrize("mt,nt", [(531, 3), (797, 5), (259, 6)])
+def test_channel_tile_fastest_keeps_the_sharers_of_an_x_panel_in_one_iteration(mt, nt):
+    """why csrc/gemm_split3.hip tile_group switches order for nt = 3 / 5 / 6: a 30-tile patch does not line up with the 32 blocks of an XCD, so many
+    X panels have their channel tiles spread over two iterations (~46 us apart on the dominant launch: the panel is fetched from HBM again -- PMC:
+    32.8 GB fetched for 12.0 GB of planes); channel-tile-fastest splits only the panels that straddle an iteration boundary (14.8 GB measured)"""
+    patch = _split_sharers(mt, nt, 36, 256, "patch")
+    chan = _split_sharers(mt, nt, 36, 256, "channel")
+    assert patch > 0.25 and chan < (nt - 1) / 32 + 0.02 and chan < patch / 2, (patch, chan)

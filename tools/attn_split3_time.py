@@ -1,3 +1,6 @@
+"""GPU probe: the split-precision ViT attention launch alone (csrc/vit.hip vit_attention_split3_kernel), B = 8 and B = 1 x 16 heads x 1037 tokens, random
+bf16 planes in, chunk-major planes out; HIP-event average of 50 launches.  A/B against another build: PF_LIB_PATH=<other libpf_hip.so>.
+usage: python tools/attn_split3_time.py   (profiles/r4_attention_swizzle.md)"""
 import os, sys, torch
 sys.path.insert(0, "/root/repo")
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))

@@ -105,6 +105,9 @@ int pf_conv_winograd_fused_timed(const pf_conv_params* p, const void* up, int nn
  * one 128 x 128 tile per block, or -- from two rounds of tiles on -- a PERSISTENT kernel (one block per CU walks its tiles) with 128 x 128 tiles
  * on a three-slot LDS ring or 192 x 192 tiles on a two-slot ring, whichever costs fewer rounds x tile cost. */
 int pf_gemm_split3(const pf_conv_params* p, void* stream);
+/* the same call with the persistent kernels capped at `grid_cap` blocks (0 = one per CU): the CUs left over run the kernels of OTHER streams
+ * (the HBM-bound Winograd transforms of the other tile batch) beside the matrix-bound GEMM */
+int pf_gemm_split3_ex(const pf_conv_params* p, int grid_cap, void* stream);
 /* which of those kernels a call would run on a chip of `cus` compute units (no launch, no GPU needed: the dispatch rule for host-side tests) */
 #define PF_S3_ROUTE_TILE64 0
 #define PF_S3_ROUTE_TILE128 1

@@ -18,6 +18,8 @@ tools/test.py:122-123 fix_random_seed):
   variants_vits: the tiny geometry with bin_centers_type / attractor_type / attractor_kind set to the values no shipped config
               uses (patchfusion.py:132-146, attractor.py:112-129), weights seed 3, image seed 11: full m1 map + coarse depth each
               (`python -m oracle.make_golden variants` regenerates only this file)
+  headline_vitl_ref: the HEADLINE architecture (DA-vitl, process 392x518) from the reference itself: one 2160x3840 image, 2x2 tiles, m1,
+              process_num=4; sampled final map + coarse depth + two coarse feature levels (`python -m oracle.make_golden vitl`; ~1-2 CPU-minutes)
 """
 import os
 import random
@@ -72,6 +74,29 @@ def cfg4k():
     np.savez_compressed(os.path.join(OUT, "cfg4k_vits.npz"), **out)
 
 
+def vitl():
+    """The HEADLINE architecture from the reference itself (round-4 review, missing #5): DA-vitl, process 392x518, one 2160x3840 image cut in
+    2x2 tiles, cai_mode m1, process_num 4 -- the reference's own PatchFusion.forward(mode='infer') (patchfusion.py:401-453; ViT-L widths
+    depth_anything.py:346-352) on the seeded weights / image every headline test uses.  Stored: 8192 sampled values of the final map, 4096 of the
+    coarse depth, 2048 of coarse feature level 3 (r2, 256 @ 112x148) and level 5 (out_conv, 32 @ 392x518), + stats.  ~1 CPU-minute on 8 threads."""
+    m, cfg, img = build("vitl", (392, 518), (2160, 3840), (2, 2))
+    lr = m.resizer(img)
+    out = {}
+    with torch.no_grad():
+        random.seed(5621)
+        cd, cf = m.coarse_forward(lr)
+        d, _ = m(mode="infer", image_lr=lr, image_hr=img, cai_mode="m1", process_num=4)
+    for name, t, k, seed in (("depth_m1", d, 8192, 21), ("coarse_depth", cd, 4096, 22), ("coarse_feat3", cf[3], 2048, 23), ("coarse_feat5", cf[5], 2048, 24)):
+        flat = t.flatten()
+        idx = sample_idx(flat.numel(), k, seed)
+        out[name + "_shape"] = np.array(t.shape, np.int64)
+        out[name + "_idx"] = idx.astype(np.int32)
+        out[name + "_val"] = flat[idx].numpy()
+        out[name + "_stats"] = np.array([t.mean().item(), t.std().item(), t.min().item(), t.max().item()], np.float32)
+        print(name, tuple(t.shape), out[name + "_stats"], flush=True)
+    np.savez_compressed(os.path.join(OUT, "headline_vitl_ref.npz"), **out)
+
+
 VARIANTS = (("normed", "inv", "mean"), ("hybrid1", "exp", "sum"), ("hybrid2", "inv", "sum"), ("softplus", "exp", "mean"))
 
 
@@ -112,6 +137,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "variants":
         variants()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "vitl":
+        vitl()
+        return
     # ---------------- tiny ----------------
     m, cfg, img = build("vits", (112, 154), (448, 616), (2, 2))
     lr = m.resizer(img)
@@ -149,6 +177,7 @@ def main():
     print("full_vits done", out["depth_m1_stats"])
     cfg4k()
     variants()
+    vitl()
 
 
 if __name__ == "__main__":

@@ -617,7 +617,13 @@ __global__ __launch_bounds__(512) void gemm_split3_persist_kernel(const pf_conv_
 //   phase 2h+1 : every wave waits for its own pieces of chunk h+1 (vmcnt(0)) before the closing barrier -- A at the end of C_A(h), B at the end of
 //                M_B(h); A reads chunk h+1 in phase 2h+2, B in 2h+3.
 // (tests/test_split3_schedule_model_cpu.py persist192 replays this control flow and asserts both rules for every chunk count.)
-template <bool BARE>
+// BL (round 5): group B issues its W pieces of chunk g+1 at the HEAD OF ITS OWN LOAD PHASE M_B(g) (phase 2g+1) instead of between the MFMAs of its
+// compute phase one phase earlier.  The register-resident microbenchmark (tools/mfma_ceiling.hip, profiles/r5_mfma_ceiling.md) shows the barrier
+// skeleton alone keeps the pipe 99.5 % busy; what idles it in the product kernel is every non-MFMA instruction of the ONE wave per SIMD that is
+// allowed to multiply -- a DMA piece stalls that wave ~100 cycles.  The slot (g+1) & 1 is free from phase 2g on (chunk g-1: read by A in 2g-2, by B
+// in 2g-1), group A reads chunk g+1 in phase 2g+2, so B's pieces have the rest of phase 2g+1 to land: they are the W planes (filters / weights,
+// L2-resident: 250-400 cycles), B waits vmcnt(0) at the end of that phase exactly as before.  Compute phases of both groups are then MFMA-only.
+template <bool BARE, bool BL>
 __global__ __launch_bounds__(512) void gemm_split3_persist192_kernel(const pf_conv_params p, int mt, int nt, int gm, int total) {
   constexpr int BM = 192, BN = 192, WM = 4, WN = 2, NP = 3, NS = 2;
   constexpr int NW = WM * WN;
@@ -815,6 +821,22 @@ __global__ __launch_bounds__(512) void gemm_split3_persist192_kernel(const pf_co
     if (++c_kc == nk) { c_kc = 0; epi_pending = true; }
   };
 
+#ifdef PF_S3_DBG
+  // timeline build (tools/persist_probe.py timeline192): waves 0 and 4 of block 0 stamp s_memtime at the seams of chunks 64 .. 95 into p.res2
+  // (8 stamps per chunk and wave, in program order; see the loops below)
+  unsigned long long* tl = nullptr;
+  if constexpr (BARE) tl = reinterpret_cast<unsigned long long*>(const_cast<void*>(p.res2));
+  const bool stamp_w = tl && blockIdx.x == 0 && (wave == 0 || wave == 4);
+#define S3_STAMP192(g, k)                                                                                     \
+  if (stamp_w && (g) >= 64 && (g) < 96) {                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                               \
+    if (lane == 0) tl[(((wave >> 2) * 32 + ((g) - 64)) << 3) + (k)] = t_;                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+  }
+#else
+#define S3_STAMP192(g, k)
+#endif
   // ---- the chunk stream
   issue();                                              // chunk 0
   vm_wait<0>();
@@ -823,19 +845,52 @@ __global__ __launch_bounds__(512) void gemm_split3_persist192_kernel(const pf_co
     // group A: M_A(g) in phase 2g, C_A(g) in phase 2g+1
 #pragma nounroll
     for (int g = 0; g < chunks; ++g) {
+      S3_STAMP192(g, 0)
       tile_cursor();
+      S3_STAMP192(g, 1)
       if (g + 1 < chunks) issue();                      // chunk g+1, phase 2g
+      S3_STAMP192(g, 2)
       read_frags();
+      S3_STAMP192(g, 3)
       lds_barrier();
+      S3_STAMP192(g, 4)
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
       multiply(std::false_type{});
       __builtin_amdgcn_s_setprio(0);
+      S3_STAMP192(g, 5)
       tile_advance();
       vm_wait<0>();                                     // this wave's pieces of chunk g+1 have landed (phase 2g+1)
+      S3_STAMP192(g, 6)
       plain_barrier();
+      S3_STAMP192(g, 7)
     }
     plain_barrier();                                    // group B's last compute phase
+  } else if constexpr (BL) {
+    // group B, pieces from its own load phase: M_B(g) in phase 2g+1 issues chunk g+1, reads chunk g; C_B(g) in phase 2g+2 is MFMA-only
+    plain_barrier();                                    // phase 0 (group A's first load phase)
+#pragma nounroll
+    for (int g = 0; g < chunks; ++g) {
+      S3_STAMP192(g, 0)
+      tile_cursor();
+      S3_STAMP192(g, 1)
+      if (g + 1 < chunks) issue();                      // W pieces of chunk g+1 -> slot (g+1) & 1, phase 2g+1
+      S3_STAMP192(g, 2)
+      read_frags();                                     // chunk g
+      S3_STAMP192(g, 3)
+      vm_wait<0>();                                     // they have landed before group A reads them in phase 2g+2
+      S3_STAMP192(g, 4)
+      lds_barrier();
+      S3_STAMP192(g, 5)
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      multiply(std::false_type{});
+      __builtin_amdgcn_s_setprio(0);
+      S3_STAMP192(g, 6)
+      tile_advance();
+      plain_barrier();
+      S3_STAMP192(g, 7)
+    }
   } else {
     // group B: one phase behind; M_B(g) in phase 2g+1, C_B(g) in phase 2g+2
     if (1 < chunks) issue();                            // chunk 1, phase 0
@@ -873,6 +928,7 @@ __global__ __launch_bounds__(512) void gemm_split3_persist192_kernel(const pf_co
 }
 
 thread_local char g_err[200] = {0};
+constexpr int PF_ERR_FALLBACK = -100;     // internal: the persistent launch is not legal for this grid, use the one-tile kernel
 
 int cu_count() {
   static std::atomic<int> cus[64];
@@ -892,15 +948,16 @@ int cu_count() {
 // would fall into DIFFERENT iterations of the 32-block XCD (46 us apart: an L2 miss each) -- those run channel-tile-fastest instead (returned as
 // gm = 0): the nt sharers of a token tile are adjacent in the order, all W panels (nt x 209 KB at K = 544) stay hot.  PF_S3_ORDER=0: the patches.
 int tile_group(int nt) {
+  const char* s = getenv("PF_S3_ORDER");
+  if (s && s[0] == '2' && nt >= 2) return 0;            // (A/B: channel tile fastest for every nt)
   if (nt == 3 || nt == 5 || nt == 6) {
-    const char* s = getenv("PF_S3_ORDER");
     if (!(s && s[0] == '0')) return 0;
   }
   return nt <= 6 ? 32 / nt : 8;
 }
 
 // persistent launch: 128 x 128 tiles, one block per CU (grid = a multiple of 8 so that every XCD has blocks)
-int launch_persist(const pf_conv_params& p, hipStream_t st) {
+int launch_persist(const pf_conv_params& p, hipStream_t st, int grid_cap) {
   constexpr int smem = 3 * 3 * (128 + 128) * 64;
   static std::atomic<unsigned long long> done{0};
   int dev = 0;
@@ -916,10 +973,12 @@ int launch_persist(const pf_conv_params& p, hipStream_t st) {
   const long total = (long)mt * nt * (p.batch > 1 ? p.batch : 1);
   const int gm = tile_group(nt);
   int grid = cu_count();
+  if (grid_cap > 0 && grid_cap < grid) grid = grid_cap;                  // (pf_gemm_split3_ex: leave CUs to a concurrent HBM-bound stream)
   if (const char* s = getenv("PF_S3_GRID")) grid = atoi(s);              // (tests: fewer blocks than CUs = more tiles per block; read per call)
   if (grid > total) grid = (int)total;
-  grid &= ~7;
-  if (grid < 8 || total > 0x7fffffffL) return PF_ERR_ARG;
+  grid &= ~7;                                                            // (8 XCDs on gfx950: the walk gives every XCD a contiguous tile range)
+  if (total > 0x7fffffffL) return PF_ERR_ARG;
+  if (grid < 8) return PF_ERR_FALLBACK;                                  // (a PF_S3_GRID below 8 / not a number: the caller runs the one-tile kernel)
 #ifdef PF_S3_DBG
   const bool bare = !p.bias && !p.scale && !p.res && p.act == PF_ACT_NONE && p.out_f32;          // (res2 = the timeline buffer)
 #else
@@ -931,15 +990,17 @@ int launch_persist(const pf_conv_params& p, hipStream_t st) {
 }
 
 // persistent 192 x 192 launch (one block per CU, 144 KiB of LDS)
-int launch_persist192(const pf_conv_params& p, hipStream_t st) {
+int launch_persist192(const pf_conv_params& p, hipStream_t st, int grid_cap) {
   constexpr int smem = 2 * 3 * (192 + 192) * 64;
   static std::atomic<unsigned long long> done{0};
   int dev = 0;
   hipGetDevice(&dev);
   const unsigned long long bit = 1ull << (dev & 63);
   if (!(done.load(std::memory_order_acquire) & bit)) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split3_persist192_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split3_persist192_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split3_persist192_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split3_persist192_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split3_persist192_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split3_persist192_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     done.fetch_or(bit, std::memory_order_release);
   }
   const long M = (long)p.B * p.OH * p.OW;
@@ -947,13 +1008,23 @@ int launch_persist192(const pf_conv_params& p, hipStream_t st) {
   const long total = (long)mt * nt * (p.batch > 1 ? p.batch : 1);
   const int gm = tile_group(nt);
   int grid = cu_count();
+  if (grid_cap > 0 && grid_cap < grid) grid = grid_cap;                  // (pf_gemm_split3_ex: leave CUs to a concurrent HBM-bound stream)
   if (const char* s = getenv("PF_S3_GRID")) grid = atoi(s);              // (tests: fewer blocks than CUs = more tiles per block; read per call)
   if (grid > total) grid = (int)total;
-  grid &= ~7;
-  if (grid < 8 || total > 0x7fffffffL) return PF_ERR_ARG;
+  grid &= ~7;                                                            // (8 XCDs on gfx950: the walk gives every XCD a contiguous tile range)
+  if (total > 0x7fffffffL) return PF_ERR_ARG;
+  if (grid < 8) return PF_ERR_FALLBACK;                                  // (a PF_S3_GRID below 8 / not a number: the caller runs the one-tile kernel)
+#ifdef PF_S3_DBG
+  const bool bare = !p.bias && !p.scale && !p.res && p.act == PF_ACT_NONE && p.out_f32;          // (res2 = the timeline buffer)
+#else
   const bool bare = !p.bias && !p.scale && !p.res && !p.res2 && p.act == PF_ACT_NONE && p.out_f32;
-  if (bare) hipLaunchKernelGGL(gemm_split3_persist192_kernel<true>, dim3((unsigned)grid), dim3(512), smem, st, p, mt, nt, gm, (int)total);
-  else hipLaunchKernelGGL(gemm_split3_persist192_kernel<false>, dim3((unsigned)grid), dim3(512), smem, st, p, mt, nt, gm, (int)total);
+#endif
+  const char* bls = getenv("PF_S3_BLOAD");                               // (A/B: 0 = group B issues between its MFMAs, the round-4 schedule)
+  const bool bl = !(bls && bls[0] == '0');
+  if (bare && bl) hipLaunchKernelGGL((gemm_split3_persist192_kernel<true, true>), dim3((unsigned)grid), dim3(512), smem, st, p, mt, nt, gm, (int)total);
+  else if (bare) hipLaunchKernelGGL((gemm_split3_persist192_kernel<true, false>), dim3((unsigned)grid), dim3(512), smem, st, p, mt, nt, gm, (int)total);
+  else if (bl) hipLaunchKernelGGL((gemm_split3_persist192_kernel<false, true>), dim3((unsigned)grid), dim3(512), smem, st, p, mt, nt, gm, (int)total);
+  else hipLaunchKernelGGL((gemm_split3_persist192_kernel<false, false>), dim3((unsigned)grid), dim3(512), smem, st, p, mt, nt, gm, (int)total);
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_LAUNCH;
 }
 
@@ -993,7 +1064,7 @@ int split3_route(const pf_conv_params& p, int cus) {
   const long planes = p.batch > 1 ? p.batch : 1;
   // (tiles of ALL planes: the 36 transform points of a small Winograd layer -- 768->768 @ 8x56x74 is 102 tiles per point, 3672 in the launch --
   // used to count per plane and fell to the 64 x 128 kernel: 0.51 ms against 0.40 through the persistent walk)
-  if (force ? force == 64 : t128 * planes < 256) return PF_S3_ROUTE_TILE64;
+  if (force ? force == 64 : t128 * planes < cus) return PF_S3_ROUTE_TILE64;
   const char* ps = getenv("PF_S3_PERSIST");
   if (!(ps && ps[0] == '0') && p.Cin >= 96 && (t128 * planes >= 2L * cus || (ps && ps[0] == '2')) && t128 * planes >= 8) {
     const char* ts = getenv("PF_S3_T192");
@@ -1015,7 +1086,11 @@ extern "C" int pf_gemm_split3_route(const pf_conv_params* p, int cus) {
 namespace {
 }  // namespace
 
-extern "C" int pf_gemm_split3(const pf_conv_params* p, void* stream) {
+extern "C" int pf_gemm_split3(const pf_conv_params* p, void* stream) { return pf_gemm_split3_ex(p, 0, stream); }
+
+// grid_cap > 0: the persistent kernels launch at most that many blocks (one per CU; rounded down to a multiple of 8), the remaining CUs stay free
+// for kernels of other streams -- the HBM-bound Winograd transforms of the other tile batch (csrc/winograd.hip run_split3).  0 = every CU.
+extern "C" int pf_gemm_split3_ex(const pf_conv_params* p, int grid_cap, void* stream) {
   const char* e = nullptr;
   if (!p || !p->x || !p->w || !p->y) return PF_ERR_ARG;
 #ifdef PF_S3_DBG
@@ -1033,7 +1108,8 @@ extern "C" int pf_gemm_split3(const pf_conv_params* p, void* stream) {
   else if (p->x_bstride <= 0 || p->w_bstride <= 0 || (!p->out_f32 && p->y_bstride <= 0)) e = "plane strides missing";
   else if (((p->korder & 2) && p->x_ld != p->Cin) || ((p->korder & 4) && p->Kpad != p->Cin) || (p->korder & ~14)) e = "chunk-major operands are dense: x_ld == Kpad == Cin";
   else if ((p->korder & 8) && (p->out_f32 || p->y_ld != p->Cout || p->Cout % 32)) e = "chunk-major output: three planes, y_ld == Cout, Cout % 32 == 0";
-  else if ((long)p->B * p->OH * p->OW * 64 >= (1L << 31) || (long)p->w_rows * 64 >= (1L << 31)) e = "too many rows for a chunk-major slab";
+  else if (((p->korder & 2) && (long)p->B * p->OH * p->OW * 64 >= (1L << 31)) || ((p->korder & 4) && (long)p->w_rows * 64 >= (1L << 31)))
+    e = "too many rows for a chunk-major slab";
 #ifdef PF_S3_DBG
   else if (p->batch > 1 && (!p->out_f32 || p->bias || p->scale || p->res || p->batch > 65535)) e = "batched planes: float32 output, no epilogue";
 #else
@@ -1043,8 +1119,16 @@ extern "C" int pf_gemm_split3(const pf_conv_params* p, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   switch (split3_route(*p, cu_count())) {
     case PF_S3_ROUTE_TILE64: return launch<64, 128, 2, 2, 2>(*p, st);
-    case PF_S3_ROUTE_PERSIST192: return launch_persist192(*p, st);
-    case PF_S3_ROUTE_PERSIST128: return launch_persist(*p, st);
+    case PF_S3_ROUTE_PERSIST192: {
+      const int rc = launch_persist192(*p, st, grid_cap);
+      if (rc != PF_ERR_FALLBACK) return rc;
+      break;
+    }
+    case PF_S3_ROUTE_PERSIST128: {
+      const int rc = launch_persist(*p, st, grid_cap);
+      if (rc != PF_ERR_FALLBACK) return rc;
+      break;
+    }
     default: break;
   }
   const char* pp = getenv("PF_S3_PP");                    // (A/B switch; read per call)

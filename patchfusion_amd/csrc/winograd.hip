@@ -232,6 +232,16 @@ int run(const pf_conv_params* p, const float* U, int u_rows, int u_kpad, float* 
   return launch_ok();
 }
 
+// one event per device shared by every stream of the process (see run_split3)
+hipEvent_t gemm_token() {
+  static hipEvent_t ev[64] = {};
+  int dev = 0;
+  hipGetDevice(&dev);
+  hipEvent_t& e = ev[dev & 63];
+  if (!e) hipEventCreateWithFlags(&e, hipEventDisableTiming);
+  return e;
+}
+
 // F(4x4,3x3) with the transform-domain GEMM in split precision: V is written as three bf16 planes, U3 = the three planes of G g G^T
 // (chunk-major [3][36][Cin/32][u_rows][32] bf16 = PackedConv.wino_u3, the split3 of packing.winograd_filters), ONE batched pf_gemm_split3 launch (plane = blockIdx.y), M float32.
 int run_split3(const pf_conv_params* p, const void* U3, int u_rows, int u_kpad, void* V3, float* M, hipStream_t st) {
@@ -253,8 +263,17 @@ int run_split3(const pf_conv_params* p, const void* U3, int u_rows, int u_kpad, 
   q.batch = A * A;                                      // transform points: x / w / y advance by one [T][Cin] / [rows][Kpad] / [T][Cout] block each
   q.x_bstride = (long)A * A * T * p->Cin;               // h / m / l plane strides
   q.w_bstride = (long)A * A * u_rows * u_kpad;
-  const int rc = pf_gemm_split3(&q, st);
+  // Overlap of the HBM-bound transforms of one tile batch with the matrix-bound GEMM of the other (two streams): the persistent GEMM
+  // leaves CUs free (PF_W3_GRID blocks instead of one per CU) and, with PF_W3_TOKEN=1, the big GEMMs of ALL streams are chained through one event in
+  // host-issue order, so that two capped GEMMs never compete for the same CUs while the transforms of the waiting stream fill the free ones.
+  int cap = 0;
+  if (const char* s = getenv("PF_W3_GRID")) cap = atoi(s);
+  hipEvent_t tok = nullptr;
+  if (const char* s = getenv("PF_W3_TOKEN")) if (s[0] == '1') tok = gemm_token();
+  if (tok) hipStreamWaitEvent(st, tok, 0);
+  const int rc = pf_gemm_split3_ex(&q, cap, st);
   if (rc != PF_OK) return rc;
+  if (tok) hipEventRecord(tok, st);
   hipLaunchKernelGGL(wino_output_kernel<MT>, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, M, p->Cout, p->bias,
                      p->act == PF_ACT_RELU ? 1 : 0, static_cast<const float*>(p->res), p->res_ld, static_cast<const float*>(p->res2),
                      p->res2_ld, static_cast<float*>(p->y), p->y_ld, p->B, p->H, p->W, TH, TW);

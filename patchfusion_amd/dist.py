@@ -31,7 +31,9 @@ def all_gather_shards(preds, n, world):
         dist.all_gather_into_tensor(out, preds[lo:hi].contiguous())       # RCCL (backend 'nccl') on GPUs, gloo in CPU tests
         return out
     qp = q + 1
-    key = (world, qp, tuple(preds.shape[1:]), preds.dtype, preds.device)
+    # n is part of the key: the compaction index `rows` depends on it (two ragged tile counts with the same qp -- world 4: n = 9 then 10 -- would
+    # otherwise reuse a stale index and return the wrong number of rows)
+    key = (world, n, tuple(preds.shape[1:]), preds.dtype, preds.device)
     buf = _GATHER_BUF.get(key)
     if buf is None:
         if len(_GATHER_BUF) > 4:

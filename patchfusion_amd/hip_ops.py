@@ -151,8 +151,11 @@ def _workspace(device, nV, nM):
 
 
 def release_workspaces():
-    """free the per-(device, stream) Winograd arenas (at the headline layer 12 GB + 8 GB per stream); they are re-grown on demand"""
+    """free the per-(device, stream) Winograd arenas (at the headline layer 12 GB + 8 GB per stream); they are re-grown on demand.  Also drops the
+    cached dispatch plans: they hold strong references to the packed layers (device weights + Winograd filter planes, several GB for ViT-L), so
+    `del model; release_workspaces(); torch.cuda.empty_cache()` really returns the memory (round-4 advisor finding)"""
     _WS.clear()
+    _CONV_CACHE.clear()
 
 
 def workspace_bytes():

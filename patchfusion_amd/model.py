@@ -166,6 +166,7 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
         self.vit_batch_all = bool(config.get("vit_batch_all", False)) or _os.environ.get("PF_VIT_BATCH_ALL", "0") == "1"
         self._engine = None
         self._coarse_state = None
+        self._pending_core_sd = [None, None]      # `core.` checkpoint tensors waiting for an external core provider (_load_branch)
         if config.load_branch:
             # patchfusion.py:105-109: each branch checkpoint is loaded with strict=True into its own sub-module
             for prefix, path in zip(("coarse_branch.", "fine_branch."), config.pretrain_model):
@@ -180,24 +181,28 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
         # still carries its weights under `core.` -- they belong to the provider, not to this module's parameter tree
         external_core = getattr(self.config[prefix[:-1]], "type", None) == 'ZoeDepth'
         unexpected = [k for k in branch_sd if k not in wanted and not (external_core and k.startswith("core."))]
-        if external_core:
-            # the core's own weights go to the injected provider, strictly, when it can take them (an nn.Module-like provider); a checkpoint that
-            # carries `core.` keys with no provider to receive them is reported -- the keys are not silently dropped (round-3 advisor finding)
-            core_sd = {k[len("core."):]: v for k, v in branch_sd.items() if k.startswith("core.") and k not in wanted}
-            if core_sd:
-                provider = self.core_providers[0 if prefix.startswith("coarse") else 1]
-                if provider is not None and hasattr(provider, "load_state_dict"):
-                    provider.load_state_dict(core_sd, strict=True)
-                else:
-                    import warnings
-                    warnings.warn(f"{prefix[:-1]}: {len(core_sd)} checkpoint tensors under 'core.' belong to the external MiDaS/BEiT core; "
-                                  f"{'the injected provider has no load_state_dict' if provider is not None else 'no core provider is set'} "
-                                  "-- they are NOT loaded (set_core_providers / core_providers=...)", stacklevel=2)
-            branch_sd = {k: v for k, v in branch_sd.items() if k in wanted}
+        # the branch's own strict check comes FIRST: a checkpoint that fails it must not have mutated the injected core (round-4 advisor finding)
         if missing or unexpected:
             raise RuntimeError(f"Error(s) in loading state_dict for {prefix[:-1]}: Missing key(s): {missing[:8]}"
                                f"{' ...' if len(missing) > 8 else ''}; Unexpected key(s): {unexpected[:8]}"
                                f"{' ...' if len(unexpected) > 8 else ''}")
+        if external_core:
+            # the core's own weights go to the injected provider, strictly, when it can take them (an nn.Module-like provider); a checkpoint that
+            # carries `core.` keys with no provider to receive them is reported AND kept: set_core_providers() re-offers it to a provider that
+            # arrives later -- the keys are not silently dropped (round-3 / round-4 advisor findings)
+            core_sd = {k[len("core."):]: v for k, v in branch_sd.items() if k.startswith("core.") and k not in wanted}
+            if core_sd:
+                which = 0 if prefix.startswith("coarse") else 1
+                provider = self.core_providers[which]
+                if provider is not None and hasattr(provider, "load_state_dict"):
+                    provider.load_state_dict(core_sd, strict=True)
+                else:
+                    import warnings
+                    self._pending_core_sd[which] = core_sd
+                    warnings.warn(f"{prefix[:-1]}: {len(core_sd)} checkpoint tensors under 'core.' belong to the external MiDaS/BEiT core; "
+                                  f"{'the injected provider has no load_state_dict' if provider is not None else 'no core provider is set'} "
+                                  "-- they are kept and handed to the provider that set_core_providers() installs", stacklevel=2)
+            branch_sd = {k: v for k, v in branch_sd.items() if k in wanted}
         return self.load_state_dict({prefix + k: v for k, v in branch_sd.items()}, strict=False)
 
     # ------------------------------------------------------------------ reference helper surface
@@ -241,6 +246,11 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
     def set_core_providers(self, coarse, fine):
         """relative-depth cores of a type-'ZoeDepth' model (see engine.ExternalCoreBranchNet)"""
         self.core_providers = (coarse, fine)
+        for which, provider in enumerate(self.core_providers):       # checkpoint `core.` tensors that arrived before the provider did
+            pend = self._pending_core_sd[which]
+            if pend is not None and provider is not None and hasattr(provider, "load_state_dict"):
+                provider.load_state_dict(pend, strict=True)
+                self._pending_core_sd[which] = None
         self._engine = None
 
     def set_compute_dtype(self, dtype):

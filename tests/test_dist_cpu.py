@@ -117,6 +117,29 @@ def _worker_mismatch(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _worker_ragged_gather(rank, world, port, out_dir):
+    """two ragged tile counts with the SAME padded shard size in one process (world 3: n = 4 then 5, both pad to 2 rows per rank;
+    then the equal-shard n = 6 and n = 4 again): the compaction index must follow n, not the padded size."""
+    _init(rank, world, port)
+    from patchfusion_amd.dist import all_gather_shards
+    ok = True
+    for n in (4, 5, 6, 4, 7, 8):
+        full = torch.arange(n * 6, dtype=torch.float32).view(n, 2, 3) + 1
+        lo, hi = tiling.shard_range(n, rank, world)
+        mine = torch.zeros_like(full)
+        mine[lo:hi] = full[lo:hi]
+        got = all_gather_shards(mine, n, world)
+        ok = ok and got.shape == full.shape and torch.equal(got, full)
+    open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "bad")
+    dist.destroy_process_group()
+
+
+def test_ragged_gather_two_tile_counts_with_equal_padded_shard_three_ranks(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker_ragged_gather, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    assert [open(tmp_path / f"rank{r}.txt").read() for r in range(3)] == ["ok"] * 3
+
+
 @pytest.mark.parametrize("mode,shard", [("m2", "kwarg"), ("m1", "config"), ("r4", "kwarg")])
 def test_two_rank_patch_sharding_matches_golden(tmp_path, golden_dir, mode, shard):
     port = _free_port()

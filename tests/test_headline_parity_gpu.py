@@ -16,10 +16,10 @@ guided-fusion U-Net, relative rms <= 1e-5 against the oracle) and one whole-net 
 (tests/dynamic_range.py: per-channel scales over 1e-3 ... 1e3 between paired layers, same function in exact arithmetic).
 The bf16 budget is 2x the measured error; profiles/r2_precision_probe.json holds the per-stage growth (features carry ~1 %
 relative rms error after 24 bf16 ViT blocks, no stage amplifies; the f32 metric-bins head maps it to 5e-4 relative depth).
-The measured numbers of each run are written to gpurun_out/r4_headline_parity.json.
+The measured numbers of each run are written to gpurun_out/r5_headline_parity.json.
 
 PF_HEADLINE_ALL=1 checks ALL 16 tiles live (two extra minutes of oracle time on the GPU; run once per round by the builder, result in
-profiles/r4_headline_parity.json) and writes tests/golden-format samples of the oracle's 16 tiles to gpurun_out/headline_vitl_sampled.npz;
+profiles/r5_headline_parity.json) and writes tests/golden-format samples of the oracle's 16 tiles to gpurun_out/headline_vitl_sampled.npz;
 the committed copy (tests/golden/headline_vitl_sampled.npz: 4096 pixels of EVERY tile + 8192 of the coarse depth) is what
 test_configs2_all_16_tiles_match_sampled_oracle_fixture checks in every run without re-running the oracle.
 """
@@ -130,7 +130,7 @@ def _record(key, rec):
     try:
         out = os.path.join(ROOT, "gpurun_out")
         os.makedirs(out, exist_ok=True)
-        path = os.path.join(out, "r4_headline_parity.json")
+        path = os.path.join(out, "r5_headline_parity.json")
         allrec = json.load(open(path)) if os.path.exists(path) else {}
         allrec[key] = rec
         json.dump(allrec, open(path, "w"), indent=1)
@@ -256,5 +256,40 @@ def test_configs2_all_16_tiles_match_sampled_oracle_fixture(golden_dir):
     print(f"MEASURED all 16 tiles vs sampled oracle: max {err.max():.3e} mean {err.mean():.3e}; per-tile max {err.max(axis=1).round(7).tolist()}; coarse max {cerr.max():.3e}")
     assert err.max() <= TOL["fp32"]["max"] and err.mean() <= TOL["fp32"]["mean"], (err.max(), err.mean())
     assert cerr.max() <= TOL_COARSE["fp32"]["max"], cerr.max()
+    del m
+    torch.cuda.empty_cache()
+
+
+def test_vitl_2x2_matches_reference_made_fixture(golden_dir):
+    """The HIP path against the REFERENCE ITSELF at the headline architecture (round-4 review, missing #5): DA-vitl, 392 x 518, one 2160 x 3840 image
+    in 2 x 2 tiles, m1, process_num 4 -- tests/golden/headline_vitl_ref.npz holds samples of what the reference's own PatchFusion.forward(mode='infer')
+    (patchfusion.py:401-453) returned for the seeded weights / image (oracle/make_golden.py vitl; the same file pins the oracle on the CPU,
+    tests/test_oracle_golden.py).  Final map and coarse depth inside the f32 budget of the headline test, two coarse feature levels at 1e-5 relative rms."""
+    import numpy as np
+    path = os.path.join(golden_dir, "headline_vitl_ref.npz")
+    g = np.load(path)
+    cfg = make_config("vitl", (392, 518), (2160, 3840), (2, 2))
+    sd = synthetic_state_dict(patchfusion_spec(cfg), 0)
+    img = torch.rand(1, 3, 2160, 3840, generator=torch.Generator().manual_seed(1234)).cuda()
+    m = PatchFusion(cfg, compute_dtype="fp32").eval()
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    with torch.no_grad():
+        lr = m.resizer(img)
+        cd, cf = m.coarse_forward(lr)
+        d, _ = m(mode="infer", image_lr=lr, image_hr=img, cai_mode="m1", process_num=4)
+    torch.cuda.synchronize()
+    rec = {}
+    for name, t in (("depth_m1", d), ("coarse_depth", cd), ("coarse_feat3", cf[3]), ("coarse_feat5", cf[5])):
+        assert tuple(t.shape) == tuple(int(v) for v in g[name + "_shape"]), (name, t.shape)
+        got = t.flatten().cpu()[torch.from_numpy(g[name + "_idx"]).long()].double().numpy()
+        ref = g[name + "_val"].astype(np.float64)
+        rec[name] = dict(max_abs=float(np.abs(got - ref).max()), mean_abs=float(np.abs(got - ref).mean()),
+                         rel_rms=float(np.sqrt(((got - ref) ** 2).mean()) / max(np.sqrt((ref ** 2).mean()), 1e-30)))
+    _record("vitl_2x2_vs_reference_fixture", rec)
+    print("MEASURED ViT-L 2x2 vs the reference-made fixture:", {k: {a: f"{b:.2e}" for a, b in v.items()} for k, v in rec.items()})
+    assert rec["depth_m1"]["max_abs"] <= TOL["fp32"]["max"] and rec["depth_m1"]["mean_abs"] <= TOL["fp32"]["mean"], rec
+    assert rec["coarse_depth"]["max_abs"] <= TOL_COARSE["fp32"]["max"], rec
+    assert rec["coarse_feat3"]["rel_rms"] <= FEATURE_REL_RMS and rec["coarse_feat5"]["rel_rms"] <= FEATURE_REL_RMS, rec
     del m
     torch.cuda.empty_cache()

@@ -149,10 +149,12 @@ def persist_pingpong(nk, tiles, wave, log, p2=0):
     log.append(("store", e_tile))
 
 
-def persist192(nk, tiles, wave, log):
+def persist192(nk, tiles, wave, log, bload=True):
     """gemm_split3_persist192_kernel (round 4, late): 192 x 192 tiles, TWO ring slots, fragments single-buffered; statement by statement the C++
-    control flow of the two wave groups.  Every wave issues its nine pieces of chunk h+1 in global phase 2h (group A from its load phase, group B
-    between the MFMAs of its compute phase) and waits for them at the end of phase 2h+1."""
+    control flow of the two wave groups.  bload=False (template BL = false, the round-4 schedule): every wave issues its nine pieces of chunk h+1 in
+    global phase 2h (group A from its load phase, group B between the MFMAs of its compute phase) and waits for them at the end of phase 2h+1.
+    bload=True (BL = true, round 5, the default): group B issues its pieces of chunk h+1 at the head of its OWN load phase 2h+1 and waits for them at
+    the end of that same phase -- both compute phases are MFMA-only."""
     chunks = tiles * nk
     P = 9
     st = {"l_load": 0, "l_kc": -1, "issued": -1}
@@ -199,6 +201,18 @@ def persist192(nk, tiles, wave, log):
             yield ("waitp", 0)
             yield ("barrier", False)
         yield ("barrier", False)
+    elif bload:
+        yield ("barrier", False)
+        for g in range(chunks):
+            tile_cursor()
+            if g + 1 < chunks:
+                begin_issue()
+                yield ("issuep", g + 1, P)
+            yield ("read", g)
+            yield ("waitp", 0)
+            yield ("barrier", True)
+            yield mfma(g)
+            yield ("barrier", False)
     else:
         if 1 < chunks:
             begin_issue()
@@ -322,12 +336,13 @@ def test_persistent_tile_walk_is_hazard_free_and_keeps_its_cursors(nk, tiles, p2
         assert stored == list(range(tiles))
 
 
+@pytest.mark.parametrize("bload", [True, False])
 @pytest.mark.parametrize("nk,tiles", [(1, 1), (1, 2), (1, 5), (2, 1), (2, 3), (3, 1), (3, 4), (4, 3), (17, 1), (17, 2), (17, 9), (32, 7), (5, 8), (24, 3)])
-def test_persist192_two_slot_ring_is_hazard_free_and_keeps_its_cursors(nk, tiles):
-    """the 192 x 192 persistent kernel: two ring slots, R1 / R2 across tile boundaries for both wave groups (group B issues from its MFMA phase),
-    loader / compute cursors and the deferred stores as in the 128 x 128 kernel"""
+def test_persist192_two_slot_ring_is_hazard_free_and_keeps_its_cursors(nk, tiles, bload):
+    """the 192 x 192 persistent kernel: two ring slots, R1 / R2 across tile boundaries for both wave groups (group B issues from the head of its own
+    load phase -- round 5 -- or, bload=False, from its MFMA phase), loader / compute cursors and the deferred stores as in the 128 x 128 kernel"""
     logs = [[] for _ in range(NW)]
-    simulate(lambda n, w: persist192(nk, tiles, w, logs[w]), nk * tiles, 2, ppw=9)
+    simulate(lambda n, w: persist192(nk, tiles, w, logs[w], bload), nk * tiles, 2, ppw=9)
     for w in range(NW):
         loads = [r for r in logs[w] if r[0] == "load"]
         assert [(r[1], r[2], r[3]) for r in loads] == [(g, g // nk, g % nk) for g in range(nk * tiles)]
@@ -342,9 +357,24 @@ def test_persist192_two_slot_ring_is_hazard_free_and_keeps_its_cursors(nk, tiles
         assert stored == list(range(tiles))
 
 
+def test_the_model_catches_a_group_b_issue_after_its_wait():
+    def broken(nk, wave):                       # group B (BL schedule) issuing its pieces AFTER the vmcnt wait of the phase: group A reads unlanded data
+        held = None
+        for ev in persist192(8, 2, wave, [], True):
+            if wave >= NW // 2 and ev[0] == "issuep" and ev[1] >= 1:
+                held = ev
+                continue
+            yield ev
+            if ev[0] == "waitp" and held is not None:
+                yield held
+                held = None
+    with pytest.raises(AssertionError, match="R1"):
+        simulate(broken, 16, 2, ppw=9)
+
+
 def test_the_model_catches_an_early_issue_into_the_two_slot_ring():
     def broken(nk, wave):                       # group B issuing chunk g+2 one phase early (from its load phase) overwrites what it is reading
-        evs = list(persist192(8, 2, wave, []))
+        evs = list(persist192(8, 2, wave, [], False))
         out = []
         for i, ev in enumerate(evs):
             if wave >= NW // 2 and ev[0] == "issuep" and ev[1] >= 2:

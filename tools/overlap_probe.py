@@ -1,0 +1,71 @@
+"""GPU probe (round 5): can the HBM-bound Winograd transforms of one tile batch run under the matrix-bound split GEMM of the other?
+Two streams run the SAME three-step Winograd layer (input transform -> batched persistent split GEMM -> output transform, csrc/winograd.hip run_split3)
+on their own tensors, host issue interleaved A, B, A, B ... (what a layer-interleaved schedule of the two tile batches would issue).  Variants:
+  grid   PF_W3_GRID: blocks of the persistent GEMM (256 = one per CU = today; fewer leave CUs to the other stream's transforms)
+  token  PF_W3_TOKEN=1: the GEMMs of both streams are chained through one event (never two capped GEMMs at once)
+Reported: ms per layer and stream (wall of 2 n layers / 2 n) against the single-stream time of the same layer (= fully serial).
+usage: python tools/overlap_probe.py [n layers per stream, default 6]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from patchfusion_amd import hip_ops, packing as pk   # noqa: E402
+from patchfusion_amd.hip_ops import ops             # noqa: E402
+
+DEV = "cuda"
+
+
+def run(layers_per_stream, streams, xs, ys, pw):
+    """issue `layers_per_stream` layers on each stream, interleaved; -> ms per layer and stream"""
+    main = torch.cuda.current_stream()
+    for s in streams:
+        s.wait_stream(main)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(main)
+    for s in streams:
+        s.wait_event(e0)
+    for _ in range(layers_per_stream):
+        for s, x, y in zip(streams, xs, ys):
+            with torch.cuda.stream(s):
+                ops.conv(x, pw, y, pad=1, act="relu")
+    for s in streams:
+        main.wait_stream(s)
+    e1.record(main)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / (layers_per_stream * len(streams))
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+    g = torch.Generator().manual_seed(0)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    variants = [(256, 0), (256, 1), (240, 1), (224, 1), (208, 1), (192, 1), (160, 1), (224, 0), (192, 0), (160, 0), (128, 0), (256, 0)]
+    print("| 3x3 layer @ B=8 | one stream ms/layer | " + " | ".join(f"grid {gr}{' +token' if tk else ''}" for gr, tk in variants) + " |")
+    print("|---|---|" + "---|" * len(variants))
+    for (cin, cout, H, W) in ((544, 544, 392, 518), (768, 768, 224, 296), (768, 256, 224, 296), (256, 256, 224, 296), (768, 768, 112, 148)):
+        w = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+        pw = pk.pack_conv(w, torch.zeros(cout), dtype=torch.float32).to(DEV)
+        xs = [torch.randn(8, H, W, cin, device=DEV) for _ in range(2)]
+        ys = [torch.empty(8, H, W, cout, device=DEV) for _ in range(2)]
+        for k in ("PF_W3_GRID", "PF_W3_TOKEN"):
+            os.environ.pop(k, None)
+        hip_ops.refresh_env()
+        run(2, [sa, sb], xs, ys, pw)                      # warm-up (workspaces of both streams)
+        one = run(n, [sa], xs[:1], ys[:1], pw)
+        cells = []
+        for gr, tk in variants:
+            os.environ["PF_W3_GRID"] = str(gr)
+            os.environ["PF_W3_TOKEN"] = str(tk)
+            run(1, [sa, sb], xs, ys, pw)
+            cells.append(run(n, [sa, sb], xs, ys, pw))
+        print(f"| {cin}->{cout} @ {H}x{W} | {one:.3f} | " + " | ".join(f"{c:.3f}" for c in cells) + " |", flush=True)
+        del xs, ys, pw
+        torch.cuda.empty_cache()
+    for k in ("PF_W3_GRID", "PF_W3_TOKEN"):
+        os.environ.pop(k, None)
+
+
+if __name__ == "__main__":
+    main()

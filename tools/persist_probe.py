@@ -137,7 +137,17 @@ def decomp():
     os.environ.pop("PF_S3_DBG", None)
 
 
-def timeline():
+def timeline192():
+    """the same stamps in the 192 x 192 kernel (round 5: group B issues its W pieces from its own load phase)"""
+    os.environ["PF_S3_T192"] = "2"
+    timeline(names_a=["tile cursor / stores", "DMA issue (9 pieces)", "27 fragment reads issued", "lgkmcnt(0) + barrier [phase ends]", "108 MFMAs",
+                      "vmcnt(0)", "closing barrier [phase ends]"],
+             names_b=["tile cursor / stores", "DMA issue (9 pieces)", "27 fragment reads issued", "vmcnt(0)", "lgkmcnt(0) + barrier [phase ends]", "108 MFMAs",
+                      "closing barrier [phase ends]"])
+    os.environ.pop("PF_S3_T192", None)
+
+
+def timeline(names_a=None, names_b=None):
     """s_memtime stamps of the persistent kernel's phases (debug build: PF_LIB_PATH=patchfusion_amd/libpf_wfdbg.so), dominant launch, block 0,
     waves 0 (group A) and 4 (group B), stream chunks 64 .. 95: where a chunk's ~2600 cycles go"""
     import ctypes as C
@@ -152,11 +162,13 @@ def timeline():
     Mw = torch.empty(36, T, cout, device=DEV)
     tl = torch.zeros(2 * 32 * 8, dtype=torch.int64, device=DEV)
     p = _lib.ConvParams()
+    V3, U3 = V3.view(3, 36, cin // 32, T, 32), U3.view(3, 36, cin // 32, rows, 32)          # chunk-major (the layout the layer uses)
     p.x, p.x_ld, p.B, p.H, p.W, p.Cin = V3.data_ptr(), cin, 1, 1, T, cin
     p.w, p.w_rows, p.Kpad = U3.data_ptr(), rows, cin
     p.y, p.y_ld, p.OH, p.OW, p.Cout = Mw.data_ptr(), cout, 1, T, cout
     p.KH = p.KW = p.stride = 1
     p.act, p.shuffle, p.dtype, p.out_f32, p.batch = 0, 1, 1, 1, 36
+    p.korder = 6
     p.x_bstride, p.w_bstride = V3.stride(0), U3.stride(0)
     p.res2 = tl.data_ptr()
     for _ in range(2):
@@ -164,9 +176,10 @@ def timeline():
     torch.cuda.synchronize()
     t = tl.cpu().view(2, 32, 8)
     names = ["epilogue/decode", "DMA issue (6 pieces)", "fragment reads issued", "vmcnt wait", "lgkmcnt(0) + barrier", "48 MFMAs", "closing barrier"]
-    print("\n| wave group | " + " | ".join(names) + " | chunk total |")
-    print("|---|" + "---|" * (len(names) + 1))
     for grp in range(2):
+        names_g = (names_a, names_b)[grp] or names
+        print("\n| wave group | " + " | ".join(names_g) + " | chunk total |")
+        print("|---|" + "---|" * (len(names_g) + 1))
         d = (t[grp, :, 1:] - t[grp, :, :-1]).double()
         tot = (t[grp, 1:, 0] - t[grp, :-1, 0]).double()
         print(f"| {'AB'[grp]} mean of 32 chunks | " + " | ".join(f"{float(d[:, i].mean()):.0f}" for i in range(7)) + f" | {float(tot.mean()):.0f} |")
@@ -186,6 +199,13 @@ def ordersweep():
 def t192sweep():
     """the 192 x 192 persistent kernel (two-slot ring, PF_S3_T192=2) against the 128 x 128 one (PF_S3_T192=0) on the same launches"""
     _sweep((("PF_S3_T192",), ("0", "2")))
+
+
+def envsweep(spec):
+    """generic interleaved per-launch A/B of one library switch: `envsweep:NAME=a,b,c` (Winograd-domain GEMMs + the ViT-L linears, PF_S3_T192=2 for the
+    latter so that every shape runs the kernel under test)"""
+    name, vals = spec.split("=", 1)
+    _sweep(((name,), tuple(vals.split(","))))
 
 
 def _sweep(knob, only_wino=False):
@@ -262,6 +282,8 @@ if __name__ == "__main__":
         sustain()
     if "timeline" in what:
         timeline()
+    if "timeline192" in what:
+        timeline192()
     if "decomp" in what:
         decomp()
     if "layers" in what:
@@ -272,3 +294,6 @@ if __name__ == "__main__":
         ordersweep()
     if "t192sweep" in what:
         t192sweep()
+    for w in what:
+        if w.startswith("envsweep:"):
+            envsweep(w.split(":", 1)[1])

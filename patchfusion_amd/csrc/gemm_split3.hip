@@ -624,7 +624,7 @@ __global__ __launch_bounds__(512) void gemm_split3_persist_kernel(const pf_conv_
 // in 2g-1), group A reads chunk g+1 in phase 2g+2, so B's pieces have the rest of phase 2g+1 to land: they are the W planes (filters / weights,
 // L2-resident: 250-400 cycles), B waits vmcnt(0) at the end of that phase exactly as before.  Compute phases of both groups are then MFMA-only.
 template <bool BARE, bool BL>
-__global__ __launch_bounds__(512) void gemm_split3_persist192_kernel(const pf_conv_params p, int mt, int nt, int gm, int total) {
+__global__ __launch_bounds__(512) void gemm_split3_persist192_kernel(const pf_conv_params p, int mt, int nt, int gm, int total, int flags) {
   constexpr int BM = 192, BN = 192, WM = 4, WN = 2, NP = 3, NS = 2;
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 16, FN = WTN / 16;
@@ -684,6 +684,7 @@ __global__ __launch_bounds__(512) void gemm_split3_persist192_kernel(const pf_co
     const int origin = is_x ? m0 : n0;
     const unsigned long long tb = op_base + (unsigned long long)z * z_b + (unsigned long long)origin * ld_b;
     const int last = lim - 1 - origin;
+
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const int pc = (wave & (WM - 1)) * PPW + i;                                // piece within this operand's three planes
@@ -711,6 +712,9 @@ __global__ __launch_bounds__(512) void gemm_split3_persist192_kernel(const pf_co
     glds16s(voff[i], sbase[i], dst_cur + i * 1024);
     sbase[i] += adv_b;
   };
+  // (Measured and NOT kept, round 5: an L2 prefetch of the X planes one chunk ahead of the pieces -- two dword LDS-DMA loads per wave and chunk touching
+  // every 128-byte line of the next chunk's rows.  0.98-1.01x on the Winograd GEMMs (profiles/r5_flags_sweep.md, flags bit 0); the ~300-cycle vmcnt(0)
+  // wait the s_memtime timeline shows after the MFMAs is the completion of the STAMP's own store, not DMA latency.)
   auto issue = [&]() __attribute__((always_inline)) {
     begin_issue();
 #pragma unroll
@@ -763,6 +767,42 @@ __global__ __launch_bounds__(512) void gemm_split3_persist192_kernel(const pf_co
   bool epi_pending = false;
   auto epilogue = [&]() __attribute__((always_inline)) {
     const long y_base = (long)e_z * M * p.y_ld;
+    if constexpr (BARE) {
+      if (flags & 2) {
+        // WHOLE-LINE stores (round 5): a fragment's store instruction writes 16 rows x 64 bytes -- sixteen half cache lines; the two channel
+        // fragments fn, fn+1 of a row are the two halves of ONE 128-byte line.  Lanes fr < 8 trade their fn+1 fragment for the fn fragment of lane
+        // fr + 8 (DPP row_ror:8, four moves), then instruction 1 writes rows 0 .. 7 and instruction 2 rows 8 .. 15 as eight FULL lines each.
+        // Same values to the same addresses (bit-identical); the store issue of a tile (~4500 cycles per wave, the longest stall of the chunk
+        // stream, profiles/r5_timeline192_bload.md) touches half as many lines per instruction.
+        const bool lo = fr < 8;
+        float* yb = reinterpret_cast<float*>(p.y) + y_base;
+#pragma unroll
+        for (int fn = 0; fn < FN; fn += 2) {
+          const int n = e_n0 + wn * WTN + (fn + (lo ? 0 : 1)) * 16 + fg * 4;
+#pragma unroll
+          for (int fm = 0; fm < FM; ++fm) {
+            const f32x4 a = acc[fn][fm], b = acc[fn + 1][fm];
+            f32x4 recv, d1, d2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float snd = lo ? b[r] : a[r];
+              recv[r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, snd), 0x128, 0xf, 0xf, false));   // row_ror:8
+              d1[r] = lo ? a[r] : recv[r];
+              d2[r] = lo ? recv[r] : b[r];
+            }
+            const int m1 = e_m0 + wm * WTM + fm * 16 + (fr & 7), m2 = m1 + 8;
+            if (n < p.Cout) {
+              if (m1 < M) *reinterpret_cast<f32x4*>(yb + (long)m1 * p.y_ld + n) = d1;
+              if (m2 < M) *reinterpret_cast<f32x4*>(yb + (long)m2 * p.y_ld + n) = d2;
+            }
+            acc[fn][fm] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[fn + 1][fm] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+        epi_pending = false;
+        return;
+      }
+    }
 #pragma unroll
     for (int fn = 0; fn < FN; ++fn) {
       const int n = e_n0 + wn * WTN + fn * 16 + fg * 4;
@@ -837,6 +877,9 @@ __global__ __launch_bounds__(512) void gemm_split3_persist192_kernel(const pf_co
 #else
 #define S3_STAMP192(g, k)
 #endif
+  // (Measured and NOT kept, round 5: staggering the block starts by up to one tile time so that the CUs do not reach their tile ends -- 147 KB of stores
+  // each -- at the same moments.  No gain (profiles/r5_flags_sweep_stagger.md): the store burst of a tile, ~4700 cycles per wave group in the s_memtime
+  // timeline against a ~1870-cycle partner phase, is bound by the CU's own store issue (~16 B/clk/CU), not by the chip-wide write bandwidth.)
   // ---- the chunk stream
   issue();                                              // chunk 0
   vm_wait<0>();
@@ -947,13 +990,16 @@ int cu_count() {
 // tiles, column by column; nt > 6: 8 token tiles x 4 channel tiles.  nt = 3, 5, 6 (30-tile patches): a third of the blocks that share an X panel
 // would fall into DIFFERENT iterations of the 32-block XCD (46 us apart: an L2 miss each) -- those run channel-tile-fastest instead (returned as
 // gm = 0): the nt sharers of a token tile are adjacent in the order, all W panels (nt x 209 KB at K = 544) stay hot.  PF_S3_ORDER=0: the patches.
+// Round 5: the same holds for the "aligned" nt (2, 4, 8, 16, 22 ...) -- the XCD ranges and per-plane tile counts are not multiples of 32, so the
+// patches split 70 % of their panels too (host replay, tests/test_split3_schedule_model_cpu.py) -- measured per launch (profiles/r5_order_sweep.md):
+// 768->768 (nt = 4) 1.07-1.18x, 768->256 / 256->256 (nt = 2) 1.03-1.06x, ViT qkv / fc1 / fc2 1.07-1.13x, the 8296 x 1024 projection 0.96x; the image
+// pass -1.0 / -3.0 ms in two interleaved A/Bs.  Channel tile fastest is therefore the default for every nt >= 2 (PF_S3_ORDER=1: the round-4 rule).
 int tile_group(int nt) {
   const char* s = getenv("PF_S3_ORDER");
-  if (s && s[0] == '2' && nt >= 2) return 0;            // (A/B: channel tile fastest for every nt)
-  if (nt == 3 || nt == 5 || nt == 6) {
-    if (!(s && s[0] == '0')) return 0;
-  }
-  return nt <= 6 ? 32 / nt : 8;
+  const char o = s ? s[0] : '2';
+  if (o == '2' && nt >= 2) return 0;                    // round 5: channel tile fastest for every nt (profiles/r5_order_sweep.md)
+  if (o == '1' && (nt == 3 || nt == 5 || nt == 6)) return 0;       // the round-4 rule
+  return nt <= 6 ? 32 / nt : 8;                         // PF_S3_ORDER=0: the patches
 }
 
 // persistent launch: 128 x 128 tiles, one block per CU (grid = a multiple of 8 so that every XCD has blocks)
@@ -1021,10 +1067,12 @@ int launch_persist192(const pf_conv_params& p, hipStream_t st, int grid_cap) {
 #endif
   const char* bls = getenv("PF_S3_BLOAD");                               // (A/B: 0 = group B issues between its MFMAs, the round-4 schedule)
   const bool bl = !(bls && bls[0] == '0');
-  if (bare && bl) hipLaunchKernelGGL((gemm_split3_persist192_kernel<true, true>), dim3((unsigned)grid), dim3(512), smem, st, p, mt, nt, gm, (int)total);
-  else if (bare) hipLaunchKernelGGL((gemm_split3_persist192_kernel<true, false>), dim3((unsigned)grid), dim3(512), smem, st, p, mt, nt, gm, (int)total);
-  else if (bl) hipLaunchKernelGGL((gemm_split3_persist192_kernel<false, true>), dim3((unsigned)grid), dim3(512), smem, st, p, mt, nt, gm, (int)total);
-  else hipLaunchKernelGGL((gemm_split3_persist192_kernel<false, false>), dim3((unsigned)grid), dim3(512), smem, st, p, mt, nt, gm, (int)total);
+  int flags = 2;                                                         // bit 1: whole-line stores of the float32 tile (A/B: PF_S3_FLAGS=0)
+  if (const char* s = getenv("PF_S3_FLAGS")) flags = atoi(s);
+  if (bare && bl) hipLaunchKernelGGL((gemm_split3_persist192_kernel<true, true>), dim3((unsigned)grid), dim3(512), smem, st, p, mt, nt, gm, (int)total, flags);
+  else if (bare) hipLaunchKernelGGL((gemm_split3_persist192_kernel<true, false>), dim3((unsigned)grid), dim3(512), smem, st, p, mt, nt, gm, (int)total, flags);
+  else if (bl) hipLaunchKernelGGL((gemm_split3_persist192_kernel<false, true>), dim3((unsigned)grid), dim3(512), smem, st, p, mt, nt, gm, (int)total, flags);
+  else hipLaunchKernelGGL((gemm_split3_persist192_kernel<false, false>), dim3((unsigned)grid), dim3(512), smem, st, p, mt, nt, gm, (int)total, flags);
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_LAUNCH;
 }
 

@@ -58,13 +58,20 @@ template <> struct Wino<4> {
 // (every 32-channel K chunk of all tiles is one slab = what the GEMM's 1-KiB DMA pieces read as whole cache lines).  Thread order for that
 // layout: 8 lanes = the 8 channel quads of one chunk of one tile (64 B of a slab row, 128 B of a pixel), 8 tiles per wave -> every store
 // of a wave is one contiguous 512-byte run of a slab; then the chunks of the same 8 tiles.
+// Grid-stride: a launch with fewer blocks than work items walks them (`total` items, blockDim.x at a time) -- the RESIDENT form (512 threads per
+// block = one block per CU at these register counts, grid = the number of CUs the transform may take) that runs beside a capped persistent GEMM of
+// the other tile batch (run_split3); a launch with one block per 256 items is the plain one-shot form.
+// (Measured and NOT kept, round 5: the plane stores as 16-byte stores -- lane pairs trading halves through DPP quad_perm so that every store instruction
+// writes a full KiB: three instructions per two transform points instead of six.  Image pass 193.0 vs 193.2 ms, the kernel's own total +3 %
+// (profiles/r5_image_ab_pair.md): at full-chip occupancy the input transform is bound by HBM, not by store issue.  Confined to 64 CUs the same kernel runs
+// 3x slower -- ~16 B/clk/CU of store issue -- which is why the transforms cannot hide on a CU subset beside the GEMM, profiles/r5_overlap_probe_resident.md.)
 template <int MT, bool SPLIT = false>
-__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int x_ld, int B, int H, int W, int C, int relu_in,
-                                                         float* __restrict__ V, int TH, int TW) {
+__global__ __launch_bounds__(512) void wino_input_kernel(const float* __restrict__ x, int x_ld, int B, int H, int W, int C, int relu_in,
+                                                         float* __restrict__ V, int TH, int TW, long total) {
   constexpr int A = MT + 2;
   const int cv = C >> 2;
   const long T = (long)B * TH * TW;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
   int c4;
   long tile;
   if constexpr (SPLIT) {
@@ -72,9 +79,9 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     const long w64 = idx >> 6;                        // (tile octet, chunk) pairs, chunk fastest
     tile = (w64 / nkc) * 8 + ((idx >> 3) & 7);
     c4 = (int)(w64 % nkc) * 8 + (int)(idx & 7);
-    if (tile >= T) return;
+    if (tile >= T) continue;
   } else {
-    if (idx >= T * cv) return;
+    if (idx >= T * cv) continue;
     c4 = (int)(idx % cv);
     tile = idx / cv;
   }
@@ -129,20 +136,20 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
       for (int j = 0; j < A; ++j)
         *reinterpret_cast<float4*>(o + (size_t)(i * A + j) * plane) = make_float4(d[i][j][0], d[i][j][1], d[i][j][2], d[i][j][3]);
   }
+  }
 }
 
 // one thread = one tile x 4 output channels: (m+2)^2 16-byte loads from the planes of M, A^T m A, then the conv epilogue in the order of
 // pf_conv (bias -> act -> + res -> + res2) and m x m 16-byte stores (bounds-checked: H, W need not be multiples of m)
 template <int MT>
-__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ M, int N, const float* __restrict__ bias, int relu,
+__global__ __launch_bounds__(512) void wino_output_kernel(const float* __restrict__ M, int N, const float* __restrict__ bias, int relu,
                                                           const float* __restrict__ res, int res_ld, const float* __restrict__ res2,
                                                           int res2_ld, float* __restrict__ y, int y_ld, int B, int H, int W, int TH,
                                                           int TW) {
   constexpr int A = MT + 2;
   const int nv = N >> 2;
   const long T = (long)B * TH * TW;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= T * nv) return;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < T * nv; idx += (long)gridDim.x * blockDim.x) {      // (grid-stride: see wino_input_kernel)
   const int n4 = (int)(idx % nv);
   const long tile = idx / nv;
   const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((long)TW * TH));
@@ -202,6 +209,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
       *reinterpret_cast<float4*>(y + pix * y_ld + n4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
     }
   }
+  }
 }
 
 inline int launch_ok() { return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_LAUNCH; }
@@ -214,7 +222,7 @@ int run(const pf_conv_params* p, const float* U, int u_rows, int u_kpad, float* 
   if (T > 0x7fffffffL) return PF_ERR_ARG;
   const long nin = T * (p->Cin / 4), nout = T * (p->Cout / 4);
   hipLaunchKernelGGL(wino_input_kernel<MT>, dim3((unsigned)((nin + 255) / 256)), dim3(256), 0, st, static_cast<const float*>(p->x), p->x_ld,
-                     p->B, p->H, p->W, p->Cin, p->relu_in, V, TH, TW);
+                     p->B, p->H, p->W, p->Cin, p->relu_in, V, TH, TW, nin);
   if (launch_ok() != PF_OK) return PF_ERR_LAUNCH;
   pf_conv_params q = {};
   q.x_ld = p->Cin; q.B = 1; q.H = 1; q.W = (int)T; q.Cin = p->Cin;
@@ -250,8 +258,13 @@ int run_split3(const pf_conv_params* p, const void* U3, int u_rows, int u_kpad, 
   const long T = (long)p->B * TH * TW;
   if (T > 0x7fffffffL) return PF_ERR_ARG;
   const long nin = ((T + 7) / 8) * 8 * (p->Cin / 4), nout = T * (p->Cout / 4);       // (input transform: whole tile octets, see the kernel)
-  hipLaunchKernelGGL((wino_input_kernel<MT, true>), dim3((unsigned)((nin + 255) / 256)), dim3(256), 0, st, static_cast<const float*>(p->x), p->x_ld,
-                     p->B, p->H, p->W, p->Cin, p->relu_in, static_cast<float*>(V3), TH, TW);
+  // PF_W3_TGRID = n > 0: the transforms run RESIDENT on n CUs (n blocks of 512 threads walking the items) instead of flooding the chip
+  int tgrid = 0;
+  if (const char* s = getenv("PF_W3_TGRID")) tgrid = atoi(s);
+  const bool resident = tgrid > 0 && nin > (long)tgrid * 512 * 4;
+  const dim3 gin = resident ? dim3((unsigned)tgrid) : dim3((unsigned)((nin + 255) / 256)), bin = resident ? dim3(512) : dim3(256);
+  hipLaunchKernelGGL((wino_input_kernel<MT, true>), gin, bin, 0, st, static_cast<const float*>(p->x), p->x_ld,
+                     p->B, p->H, p->W, p->Cin, p->relu_in, static_cast<float*>(V3), TH, TW, nin);
   if (launch_ok() != PF_OK) return PF_ERR_LAUNCH;
   pf_conv_params q = {};
   q.x_ld = p->Cin; q.B = 1; q.H = 1; q.W = (int)T; q.Cin = p->Cin;
@@ -274,7 +287,8 @@ int run_split3(const pf_conv_params* p, const void* U3, int u_rows, int u_kpad, 
   const int rc = pf_gemm_split3_ex(&q, cap, st);
   if (rc != PF_OK) return rc;
   if (tok) hipEventRecord(tok, st);
-  hipLaunchKernelGGL(wino_output_kernel<MT>, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, M, p->Cout, p->bias,
+  const bool resident_out = tgrid > 0 && nout > (long)tgrid * 512 * 4;
+  hipLaunchKernelGGL(wino_output_kernel<MT>, resident_out ? dim3((unsigned)tgrid) : dim3((unsigned)((nout + 255) / 256)), resident_out ? dim3(512) : dim3(256), 0, st, M, p->Cout, p->bias,
                      p->act == PF_ACT_RELU ? 1 : 0, static_cast<const float*>(p->res), p->res_ld, static_cast<const float*>(p->res2),
                      p->res2_ld, static_cast<float*>(p->y), p->y_ld, p->B, p->H, p->W, TH, TW);
   return launch_ok();

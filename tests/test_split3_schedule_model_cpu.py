@@ -387,10 +387,12 @@ def test_the_model_catches_an_early_issue_into_the_two_slot_ring():
         simulate(broken, 16, 2, ppw=9)
 
 
-def _persist_tiles(mt, nt, planes, G):
-    """host + device tile walk of gemm_split3_persist_kernel: returns, per block, the (z, tile_m, tile_n) it visits, in order"""
+def _persist_tiles(mt, nt, planes, G, order=2):
+    """host + device tile walk of gemm_split3_persist_kernel: returns, per block, the (z, tile_m, tile_n) it visits, in order.  order = PF_S3_ORDER:
+    2 (default, round 5) channel tile fastest for every nt >= 2, 1 the round-4 rule (nt = 3 / 5 / 6 only), 0 the gm x nt patches"""
     total = mt * nt * planes
-    gm = 0 if nt in (3, 5, 6) else (32 // nt if nt <= 6 else 8)       # csrc/gemm_split3.hip tile_group: 0 = channel tile fastest
+    ctf = (order == 2 and nt >= 2) or (order == 1 and nt in (3, 5, 6))
+    gm = 0 if ctf else (32 // nt if nt <= 6 else 8)                  # csrc/gemm_split3.hip tile_group: 0 = channel tile fastest
     per_plane, per_group = mt * nt, gm * nt
     out = []
     for b in range(G):
@@ -415,8 +417,9 @@ def _persist_tiles(mt, nt, planes, G):
 
 @pytest.mark.parametrize("mt,nt,planes,G", [(797, 5, 36, 256), (65, 24, 1, 256), (65, 8, 1, 256), (9, 5, 1, 16), (8, 2, 5, 40), (5, 2, 3, 8), (17, 1, 1, 8),
                                             (259, 6, 36, 256), (65, 32, 1, 248), (3, 7, 2, 24), (531, 3, 36, 256), (44, 16, 1, 256)])
-def test_persistent_tile_walk_covers_every_tile_once(mt, nt, planes, G):
-    walks = _persist_tiles(mt, nt, planes, G)
+@pytest.mark.parametrize("order", [2, 1, 0])
+def test_persistent_tile_walk_covers_every_tile_once(mt, nt, planes, G, order):
+    walks = _persist_tiles(mt, nt, planes, G, order)
     seen = [t for w in walks for t in w]
     assert len(seen) == mt * nt * planes == len(set(seen))
     assert all(0 <= z < planes and 0 <= m < mt and 0 <= n < nt for z, m, n in seen)

@@ -1,0 +1,15 @@
+#!/bin/bash
+# round 5, call 4: L2 prefetch of the X planes (flags bit 0) and whole-line stores (bit 1) in the 192-tile kernel; tile order per nt
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+mkdir -p gpurun_out; export TMPDIR=/tmp
+O=gpurun_out
+( timeout 900 python -m pytest tests/test_hip_ops_gpu.py -m gpu -q -x -k "gemm_split3 or conv_winograd" 2>&1 | tail -8 ) > $O/r5d_checks.log 2>&1
+echo "== checks"; cat $O/r5d_checks.log
+( PF_S3_T192=2 timeout 600 python tools/persist_probe.py envsweep:PF_S3_FLAGS=0,1,2,3 ) > $O/r5d_flags_sweep.md 2>&1
+echo "== flags sweep"; cat $O/r5d_flags_sweep.md
+( timeout 600 python tools/persist_probe.py envsweep:PF_S3_ORDER=1,2 ) > $O/r5d_order_sweep.md 2>&1
+echo "== order sweep"; cat $O/r5d_order_sweep.md
+( PF_LIB_PATH=patchfusion_amd/libpf_wfdbg.so timeout 300 python tools/persist_probe.py timeline192 ) > $O/r5d_timeline192.md 2>&1
+echo "== timeline"; cat $O/r5d_timeline192.md
+( timeout 600 python tools/image_ab.py --steps 4 --rounds 3 "PF_S3_FLAGS=0" "PF_S3_FLAGS=3" "PF_S3_FLAGS=3,PF_S3_ORDER=2" "PF_S3_FLAGS=1,PF_S3_ORDER=2" ) > $O/r5d_image_ab.md 2> $O/r5d_image_ab.err
+echo "== image ab"; cat $O/r5d_image_ab.md; tail -3 $O/r5d_image_ab.err

@@ -3,6 +3,7 @@ Two streams run the SAME three-step Winograd layer (input transform -> batched p
 on their own tensors, host issue interleaved A, B, A, B ... (what a layer-interleaved schedule of the two tile batches would issue).  Variants:
   grid   PF_W3_GRID: blocks of the persistent GEMM (256 = one per CU = today; fewer leave CUs to the other stream's transforms)
   token  PF_W3_TOKEN=1: the GEMMs of both streams are chained through one event (never two capped GEMMs at once)
+  T      PF_W3_TGRID: the transforms as RESIDENT kernels on that many CUs (grid-stride) instead of one-shot launches that flood every free CU
 Reported: ms per layer and stream (wall of 2 n layers / 2 n) against the single-stream time of the same layer (= fully serial).
 usage: python tools/overlap_probe.py [n layers per stream, default 6]"""
 import os
@@ -41,29 +42,36 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 6
     g = torch.Generator().manual_seed(0)
     sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
-    variants = [(256, 0), (256, 1), (240, 1), (224, 1), (208, 1), (192, 1), (160, 1), (224, 0), (192, 0), (160, 0), (128, 0), (256, 0)]
-    print("| 3x3 layer @ B=8 | one stream ms/layer | " + " | ".join(f"grid {gr}{' +token' if tk else ''}" for gr, tk in variants) + " |")
-    print("|---|---|" + "---|" * len(variants))
+    # (GEMM grid, token, transform grid: 0 = one-shot transforms flooding the chip, n = resident on n CUs)
+    variants = [(256, 0, 0), (192, 1, 64), (192, 1, 80), (176, 1, 80), (160, 1, 96), (208, 1, 48), (224, 1, 32), (192, 0, 64), (176, 0, 80), (192, 1, 0), (256, 0, 0)]
+    print("| 3x3 layer @ B=8 | one stream ms/layer | one stream, transforms resident on 64 / 96 CUs | "
+          + " | ".join(f"G {gr}{' +token' if tk else ''} T {tg or 'flood'}" for gr, tk, tg in variants) + " |")
+    print("|---|---|---|" + "---|" * len(variants))
     for (cin, cout, H, W) in ((544, 544, 392, 518), (768, 768, 224, 296), (768, 256, 224, 296), (256, 256, 224, 296), (768, 768, 112, 148)):
         w = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
         pw = pk.pack_conv(w, torch.zeros(cout), dtype=torch.float32).to(DEV)
         xs = [torch.randn(8, H, W, cin, device=DEV) for _ in range(2)]
         ys = [torch.empty(8, H, W, cout, device=DEV) for _ in range(2)]
-        for k in ("PF_W3_GRID", "PF_W3_TOKEN"):
+        for k in ("PF_W3_GRID", "PF_W3_TOKEN", "PF_W3_TGRID"):
             os.environ.pop(k, None)
         hip_ops.refresh_env()
         run(2, [sa, sb], xs, ys, pw)                      # warm-up (workspaces of both streams)
         one = run(n, [sa], xs[:1], ys[:1], pw)
+        os.environ["PF_W3_TGRID"] = "64"
+        one64 = run(n, [sa], xs[:1], ys[:1], pw)
+        os.environ["PF_W3_TGRID"] = "96"
+        one96 = run(n, [sa], xs[:1], ys[:1], pw)
         cells = []
-        for gr, tk in variants:
+        for gr, tk, tg in variants:
             os.environ["PF_W3_GRID"] = str(gr)
             os.environ["PF_W3_TOKEN"] = str(tk)
+            os.environ["PF_W3_TGRID"] = str(tg)
             run(1, [sa, sb], xs, ys, pw)
             cells.append(run(n, [sa, sb], xs, ys, pw))
-        print(f"| {cin}->{cout} @ {H}x{W} | {one:.3f} | " + " | ".join(f"{c:.3f}" for c in cells) + " |", flush=True)
+        print(f"| {cin}->{cout} @ {H}x{W} | {one:.3f} | {one64:.3f} / {one96:.3f} | " + " | ".join(f"{c:.3f}" for c in cells) + " |", flush=True)
         del xs, ys, pw
         torch.cuda.empty_cache()
-    for k in ("PF_W3_GRID", "PF_W3_TOKEN"):
+    for k in ("PF_W3_GRID", "PF_W3_TOKEN", "PF_W3_TGRID"):
         os.environ.pop(k, None)
 
 

@@ -45,6 +45,7 @@ sys.path.insert(0, ROOT)
 
 SPLITS = {1: (4, 4), 2: (4, 8), 4: (8, 8), 8: (8, 8)}
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # MI355X_MICROARCH.md: dense MFMA peaks
+PRACTICAL_BF16_TFLOPS = 2020.0                     # measured on this chip, random h / m / l operands, register-resident v_mfma_f32_16x16x32_bf16 (profiles/r5_mfma_ceiling.md)
 DTYPE_NAME = {"fp32": "f32", "bf16": "bf16"}
 
 T0 = time.time()
@@ -70,7 +71,13 @@ def main():
     ap.add_argument("--roofline-only", action="store_true", help="only time the dominant kernel (kernel tuning aid)")
     ap.add_argument("--gemm-sweep", action="store_true", help="time the ViT-L linear layers / other shapes (kernel tuning aid)")
     ap.add_argument("--only", default="", help="gemm-sweep: comma separated shape names to run")
+    ap.add_argument("--dry-run", action="store_true", default=os.environ.get("PF_BENCH_DRY_RUN", "0") == "1",
+                    help="the launch line, rendezvous, tile sharding, all-gather, timing protocol and JSON line of a --gpus N run WITHOUT GPUs: gloo backend, "
+                         "CPU tensors, the torch stand-in op set of the CPU tests (tests/fake_ops.py) on a tiny ViT-S geometry with the SAME tile grid.  "
+                         "Its numbers mean nothing (`dry_run: true`); tests/test_bench_dry_run_cpu.py runs the driver's 8-rank command through it")
     args = ap.parse_args()
+    if args.dry_run:
+        return dry_run(args)
 
     if args.gemm_sweep:
         torch.cuda.set_device(0)
@@ -168,7 +175,8 @@ def main():
     }
 
     out["memory"] = dict(mem[args.dtype], note="torch allocator peak on rank 0 over warm-up + timed steps: weights (two f32 checkpoints + packed "
-                         "copies), activations of process_num tiles on two streams, the three-step Winograd V/M arenas (one pair per stream)")
+                         "copies), activations of process_num tiles on two streams, the three-step Winograd V/M arenas (one pair per stream, capped at "
+                         "PF_WS_CAP_GB = 2.5 GB: larger layers run as sub-batches of their tiles); PatchFusion.free_parameters() (opt-in) returns another ~2.7 GB")
     if world > 1:
         out["rank_seconds"] = rank_s[args.dtype]
     if rank == 0 and not args.no_roofline:
@@ -209,6 +217,71 @@ def main():
     if world > 1:
         barrier()                      # the other ranks wait for rank 0's roofline launch, then all leave together
         torch.distributed.destroy_process_group()
+
+
+def dry_run(args):
+    """see --dry-run: every line of the multi-rank protocol of main() (env rendezvous, shard_patches model, barrier + max-over-ranks timing, per-rank
+    seconds, rank 0 prints ONE JSON line, common exit) on CPU tensors."""
+    import torch.distributed as dist
+    from patchfusion_amd.config import make_config
+    from patchfusion_amd.model import PatchFusion
+    from patchfusion_amd.spec import patchfusion_spec, synthetic_state_dict
+    from tests.fake_ops import ops as fake_ops
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    torch.set_num_threads(1)
+    if world > 1:
+        dist.init_process_group("gloo")
+    N = max(world, 1)
+    assert args.gpus == N or world == 1, "launch with torch.distributed.run for --gpus > 1"
+    split = tuple(int(v) for v in args.split.split("x")) if args.split else SPLITS.get(N, (4, 4))
+    ps = (112, 154)
+    raw = (ps[0] * split[0], ps[1] * split[1])          # the same tile GRID as the real run on a tiny geometry
+    cfg = make_config("vits", ps, raw, split)
+    sd = synthetic_state_dict(patchfusion_spec(cfg), 0)
+    img = torch.rand(1, 3, *raw, generator=torch.Generator().manual_seed(1234))
+    P = split[0] * split[1]
+    model = PatchFusion(cfg, compute_dtype="fp32", ops=fake_ops, shard_patches=world > 1).eval()
+    model.load_state_dict(sd, strict=True)
+    lr = model.resizer(img)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    d = None
+    for _ in range(args.warmup):
+        d, _x = model(mode="infer", image_lr=lr, image_hr=img, cai_mode="m1", process_num=args.process_num)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        d, _x = model(mode="infer", image_lr=lr, image_hr=img, cai_mode="m1", process_num=args.process_num)
+    barrier()
+    dt = time.perf_counter() - t0
+    rank_s = [round(dt, 4)]
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        rank_s = [round(float(v.item()), 4) for v in every]
+        dt = max(rank_s)
+        # every rank holds the SAME stitched map (the gather is an all-gather): checksum over the ranks
+        c = torch.tensor([float(d.double().sum())], dtype=torch.float64)
+        cs = [torch.zeros_like(c) for _ in range(world)]
+        dist.all_gather(cs, c)
+        assert all(float(v) == float(cs[0]) for v in cs), "ranks disagree on the stitched map"
+    if rank == 0:
+        print(json.dumps({
+            "metric": "patches/sec (DRY RUN of the multi-rank protocol on CPU tensors -- not a measurement)", "value": round(P * args.steps / dt, 3),
+            "unit": "patches/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak" if N <= 4 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "dry_run": True, "rank_seconds": rank_s, "depth_shape": list(d.shape),
+            "config": {"workload": f"DRY RUN: Depth-Anything-vits14 geometry {ps[0]}x{ps[1]}, {raw[0]}x{raw[1]} image, {split[0]}x{split[1]} tiles "
+                                   f"({P} tiles, {P // N} per rank), gloo, torch stand-in ops",
+                       "parallelism": f"patch-sharded x{N}, coarse+G2L replicated, gloo all_gather of tile depths" if N > 1 else "single process"}}), flush=True)
+    if world > 1:
+        barrier()
+        dist.destroy_process_group()
 
 
 PRECISION_F32 = {
@@ -304,10 +377,15 @@ def roofline(dtype, dev, gemm_only=False):
         # points -> output transform.  Dominant launch = that GEMM (round 4: gemm_split3_persist192_kernel, v_mfma_f32_16x16x32_bf16 x 6 per useful product):
         # priced as its USEFUL float32 multiply-adds 36 * 2 * T * C * C against the f32 MFMA peak -- the roofline of the arithmetic the layer
         # asks for -- with the executed bf16 rate against the bf16 peak beside it.
-        T = B * -(-H // 4) * -(-W // 4)
+        # (round 5: the engine runs a layer whose V + M arenas exceed PF_WS_CAP_GB as sub-batches of its images, hip_ops.wino3_subbatches -- the launch
+        # timed here is the launch the pass issues: Bs = B / ns images per launch, ns launches per layer call)
+        ns = hip_ops.wino3_subbatches(B, H, W, pw)[0]
+        Bs = B // ns
+        T = Bs * -(-H // 4) * -(-W // 4)
         V3 = torch.randn(3, 36, C // 32, T, 32, device=dev).to(torch.bfloat16)       # chunk-major planes, as the input transform writes them
         Mw = torch.empty(36 * T * C, device=dev)
-        ms = ops.gemm_planes_split3_timed(V3, pw.wino_u3, Mw.view(36, T, C), T, C, C, 5)
+        iters = 5 * ns                    # (the same ~50 ms of launches whatever the sub-batch: a 13 ms window of short launches reads ~10 % slow -- clock ramp)
+        ms = ops.gemm_planes_split3_timed(V3, pw.wino_u3, Mw.view(36, T, C), T, C, C, iters)
         flops = 36 * 2.0 * T * C * C
         ach = flops / (ms * 1e-3) / 1e12
         del V3, Mw
@@ -317,9 +395,9 @@ def roofline(dtype, dev, gemm_only=False):
             y = torch.empty(B, H, W, C, device=dev)
             ms_layer = ops.conv(x, pw, y, pad=1, act="relu", _timed=5)
         try:
-            with open(os.path.join(ROOT, "profiles", "r4_pmc_dominant_fp32.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r5_pmc_dominant_fp32.json")) as f:
                 j = json.load(f)
-            traffic = j["derived"]["traffic_bytes"] if j.get("kernel_source_sha") == kernel_source_sha() else None
+            traffic = j["derived"]["traffic_bytes"] if (j.get("kernel_source_sha") == kernel_source_sha() and j.get("ws_cap_gb") == os.environ.get("PF_WS_CAP_GB", "2.5")) else None
         except Exception:
             traffic = None
         # the pipe this launch executes on is the bf16 MFMA, six instructions per useful float32 product: its ceiling for float32-grade work
@@ -328,16 +406,21 @@ def roofline(dtype, dev, gemm_only=False):
         peak = PEAK_TFLOPS["bf16"] / 6.0
         return {"bound": "mfma",
                 "kernel": f"gemm_split3_persist192_kernel (persistent 192 x 192 tiles, 6 x v_mfma_f32_16x16x32_bf16 per float32 product, f32 accumulation) as the batched transform-domain GEMM of the "
-                          f"largest layer: 36 planes x [{T} x {C}].[{C} x {C}] = 3x3 {C}->{C} @ {B}x{H}x{W} (GuidedFusion up-conv) under Winograd F(4x4,3x3)",
+                          f"largest layer: 36 planes x [{T} x {C}].[{C} x {C}] = 3x3 {C}->{C} @ {Bs}x{H}x{W} (GuidedFusion up-conv under Winograd F(4x4,3x3); the layer call over "
+                          f"{B} tiles issues {ns} such launches: workspace cap PF_WS_CAP_GB)",
                 "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "traffic": traffic, "winograd_m": 4,
+                # the dense bf16 MFMA rate this chip SUSTAINS on random operands, measured with a register-resident stream (tools/mfma_ceiling.hip,
+                # profiles/r5_mfma_ceiling.md: 2020 TF/s at 2.05 GHz with the h / m / l operand pattern; zeros 2467 at 2.39 GHz) -- the practical ceiling beside the
+                # nominal one.  `frac` stays against the nominal peak.
+                "practical_peak": round(PRACTICAL_BF16_TFLOPS / 6.0, 1), "frac_of_practical_peak": round(ach / (PRACTICAL_BF16_TFLOPS / 6.0), 4),
+                "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "launches_per_layer_call": ns, "calls": iters + 1, "traffic": traffic, "winograd_m": 4,
                 "note": "achieved = USEFUL float32 FLOPs of the launch per second; peak = the dense bf16 MFMA peak / 6 (six bf16 MFMAs per float32-grade "
                         "product), so frac = executed bf16 FLOPs (padding columns not counted) over the 2.5 PF/s bf16 peak",
                 "vs_f32_mfma_peak": round(ach / PEAK_TFLOPS["fp32"], 4),
                 "executed_bf16": {"tflops": round(6 * ach, 1), "peak": PEAK_TFLOPS["bf16"], "frac": round(6 * ach / PEAK_TFLOPS["bf16"], 4)},
                 "layer": None if ms_layer is None else {
-                    "what": f"whole layer = input transform (split planes) + batched GEMM + output transform/epilogue, 3x3 {C}->{C} @ {B}x{H}x{W}",
-                    "ms": round(ms_layer, 4), "transforms_ms": round(ms_layer - ms, 4), "direct_conv_flops": direct_flops,
+                    "what": f"whole layer = input transform (split planes) + batched GEMM + output transform/epilogue, 3x3 {C}->{C} @ {B}x{H}x{W} ({ns} sub-batches)",
+                    "ms": round(ms_layer, 4), "transforms_ms": round(ms_layer - ns * ms, 4), "direct_conv_flops": direct_flops,
                     "direct_conv_tflops_equivalent": round(direct_flops / (ms_layer * 1e-3) / 1e12, 2)}}
     if pw.wino_up is not None and pk.winograd_applies(pw, B * H * W, 1, 1, "relu") and hip_ops._fused_wanted(B, H, W, pw):
         # round 3: the layer is ONE kernel (csrc/wino_fused.hip): its own multiply-adds = 36 transform points x 2 x T x C x C with

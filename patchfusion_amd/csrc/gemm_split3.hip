@@ -685,11 +685,13 @@ __global__ __launch_bounds__(512) void gemm_split3_persist192_kernel(const pf_co
     const unsigned long long tb = op_base + (unsigned long long)z * z_b + (unsigned long long)origin * ld_b;
     const int last = lim - 1 - origin;
 
+    int lane_o = lane;                                    // (opaque copy: the per-piece row constants are recomputed at every tile switch instead of
+    asm volatile("" : "+v"(lane_o));                      //  being hoisted out of the chunk loop, where nine more live registers would spill)
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const int pc = (wave & (WM - 1)) * PPW + i;                                // piece within this operand's three planes
-      const int row = pc * 16 + (lane >> 2);
-      const int j = (lane & 3) ^ ((row >> 1) & 3);                               // (BM is a multiple of 8: same swizzle as the stage row)
+      const int row = pc * 16 + (lane_o >> 2);
+      const int j = (lane_o & 3) ^ ((row >> 1) & 3);                             // (BM is a multiple of 8: same swizzle as the stage row)
       const int pl = pc / (BM / 16), r = row - pl * BM;
       sbase[i] = tb + pl * pl_b;
       voff[i] = (unsigned)(min(r, last) * ld_b + j * 16);
@@ -765,87 +767,103 @@ __global__ __launch_bounds__(512) void gemm_split3_persist192_kernel(const pf_co
   int l_comp = l_first, c_kc = 0;
   int e_z = 0, e_m0 = 0, e_n0 = 0;
   bool epi_pending = false;
+  // Epilogue on EXCHANGED fragments (round 5).  A fragment's store instruction would write 16 rows x 64 bytes -- sixteen half cache lines; the two channel
+  // fragments fn, fn+1 of a row are the two halves of ONE 128-byte line.  Lanes fr < 8 trade their fn+1 fragment for the fn fragment of lane fr + 8 (DPP
+  // row_ror:8, four moves); each lane then owns rows fr & 7 and (fr & 7) + 8 of ONE 4-channel group.  Everything after the accumulation is elementwise,
+  // so bias -> act -> scale -> residual(s) run on the exchanged values (a single bias / scale vector per lane; residual loads are whole lines too):
+  //   float32 output: two 16-byte stores per fragment pair, eight FULL lines each;
+  //   plane output, chunk-major (the ViT block's qkv / fc1): a lane's share of a plane row is 8 bytes.  v_permlane16_swap_b32 trades words between lanes
+  //   16 apart = the adjacent 4-channel group of the same row: swap(h, m) leaves the even group with 16 bytes of plane h and the odd group with 16 bytes
+  //   of plane m; the l words of the lane's two rows pair up the same way -- three full 16-byte store instructions where six 8-byte ones were;
+  //   plane output, row-major (tests): plain 8-byte stores.
+  // Same bits to the same addresses as a fragment-by-fragment epilogue.
   auto epilogue = [&]() __attribute__((always_inline)) {
     const long y_base = (long)e_z * M * p.y_ld;
-    if constexpr (BARE) {
-      if (flags & 2) {
-        // WHOLE-LINE stores (round 5): a fragment's store instruction writes 16 rows x 64 bytes -- sixteen half cache lines; the two channel
-        // fragments fn, fn+1 of a row are the two halves of ONE 128-byte line.  Lanes fr < 8 trade their fn+1 fragment for the fn fragment of lane
-        // fr + 8 (DPP row_ror:8, four moves), then instruction 1 writes rows 0 .. 7 and instruction 2 rows 8 .. 15 as eight FULL lines each.
-        // Same values to the same addresses (bit-identical); the store issue of a tile (~4500 cycles per wave, the longest stall of the chunk
-        // stream, profiles/r5_timeline192_bload.md) touches half as many lines per instruction.
-        const bool lo = fr < 8;
-        float* yb = reinterpret_cast<float*>(p.y) + y_base;
+    int fr = lane & 15, fg = lane >> 4;                  // (re-derived behind an opaque barrier: everything computed from them stays INSIDE the
+    asm volatile("" : "+v"(fr), "+v"(fg));               //  epilogue -- hoisted out of the chunk loop these values spill the loader's piece offsets)
+    const bool lo = fr < 8, oddg = fg & 1;
 #pragma unroll
-        for (int fn = 0; fn < FN; fn += 2) {
-          const int n = e_n0 + wn * WTN + (fn + (lo ? 0 : 1)) * 16 + fg * 4;
-#pragma unroll
-          for (int fm = 0; fm < FM; ++fm) {
-            const f32x4 a = acc[fn][fm], b = acc[fn + 1][fm];
-            f32x4 recv, d1, d2;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float snd = lo ? b[r] : a[r];
-              recv[r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, snd), 0x128, 0xf, 0xf, false));   // row_ror:8
-              d1[r] = lo ? a[r] : recv[r];
-              d2[r] = lo ? recv[r] : b[r];
-            }
-            const int m1 = e_m0 + wm * WTM + fm * 16 + (fr & 7), m2 = m1 + 8;
-            if (n < p.Cout) {
-              if (m1 < M) *reinterpret_cast<f32x4*>(yb + (long)m1 * p.y_ld + n) = d1;
-              if (m2 < M) *reinterpret_cast<f32x4*>(yb + (long)m2 * p.y_ld + n) = d2;
-            }
-            acc[fn][fm] = f32x4{0.f, 0.f, 0.f, 0.f};
-            acc[fn + 1][fm] = f32x4{0.f, 0.f, 0.f, 0.f};
-          }
-        }
-        epi_pending = false;
-        return;
-      }
-    }
-#pragma unroll
-    for (int fn = 0; fn < FN; ++fn) {
-      const int n = e_n0 + wn * WTN + fn * 16 + fg * 4;
+    for (int fn = 0; fn < FN; fn += 2) {
+      __builtin_amdgcn_sched_barrier(0);                 // one fragment pair at a time (register pressure)
+      const int n = e_n0 + wn * WTN + (fn + (lo ? 0 : 1)) * 16 + fg * 4;
+      const bool nok = n < p.Cout;
       float4 bias_r = make_float4(0.f, 0.f, 0.f, 0.f), scale_r = make_float4(1.f, 1.f, 1.f, 1.f);
       if constexpr (!BARE) {
-        __builtin_amdgcn_sched_barrier(0);                 // one channel fragment at a time (register pressure)
-        if (n < p.Cout) {
+        if (nok) {
           if (p.bias) bias_r = *reinterpret_cast<const float4*>(p.bias + n);
           if (p.scale) scale_r = *reinterpret_cast<const float4*>(p.scale + n);
         }
       }
 #pragma unroll
       for (int fm = 0; fm < FM; ++fm) {
-        const int m = e_m0 + wm * WTM + fm * 16 + fr;
-        if (m < M && n < p.Cout) {
-          if constexpr (BARE) {
-            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + y_base + (long)m * p.y_ld + n) = acc[fn][fm];
-          } else {
-            float v[4] = {acc[fn][fm][0] + bias_r.x, acc[fn][fm][1] + bias_r.y, acc[fn][fm][2] + bias_r.z, acc[fn][fm][3] + bias_r.w};
+        const f32x4 a = acc[fn][fm], b = acc[fn + 1][fm];
+        acc[fn][fm] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[fn + 1][fm] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float v[2][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float snd = lo ? b[r] : a[r];
+          const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, snd), 0x128, 0xf, 0xf, false));   // row_ror:8
+          v[0][r] = lo ? a[r] : recv;
+          v[1][r] = lo ? recv : b[r];
+        }
+        const int m1 = e_m0 + wm * WTM + fm * 16 + (fr & 7);
+        if constexpr (BARE) {
+          float* yb = reinterpret_cast<float*>(p.y) + y_base;
+          if (nok && m1 < M) *reinterpret_cast<float4*>(yb + (long)m1 * p.y_ld + n) = make_float4(v[0][0], v[0][1], v[0][2], v[0][3]);
+          if (nok && m1 + 8 < M) *reinterpret_cast<float4*>(yb + (long)(m1 + 8) * p.y_ld + n) = make_float4(v[1][0], v[1][1], v[1][2], v[1][3]);
+        } else {
+          const float bs[4] = {bias_r.x, bias_r.y, bias_r.z, bias_r.w}, sc[4] = {scale_r.x, scale_r.y, scale_r.z, scale_r.w};
+          const int ne = n - (oddg ? 4 : 0);              // chunk-major plane output: the pair's 8 channels start at the even group
+          uint32_t lw[2][2];                              // l words of the two rows (plane output)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {                   // one row at a time (register pressure)
+            __builtin_amdgcn_sched_barrier(0);
+            const int m = m1 + 8 * h;
+            const bool ok = nok && m < M;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[h][r] += bs[r];
             if (p.act == PF_ACT_RELU) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+              for (int r = 0; r < 4; ++r) v[h][r] = fmaxf(v[h][r], 0.f);
             } else if (p.act == PF_ACT_GELU) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+              for (int r = 0; r < 4; ++r) v[h][r] = gelu_erf(v[h][r]);
             } else if (p.act == PF_ACT_SOFTPLUS) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = softplus20(v[r]);
+              for (int r = 0; r < 4; ++r) v[h][r] = softplus20(v[h][r]);
             }
-            v[0] *= scale_r.x; v[1] *= scale_r.y; v[2] *= scale_r.z; v[3] *= scale_r.w;
-            if (p.res) {
-              const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) + (long)m * p.res_ld + n);
-              v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[h][r] *= sc[r];
+            if (p.res && ok) {
+              const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) + (long)m * p.res_ld + n);
+              v[h][0] += q.x; v[h][1] += q.y; v[h][2] += q.z; v[h][3] += q.w;
             }
-            if (p.res2) {
-              const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res2) + (long)m * p.res2_ld + n);
-              v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+            if (p.res2 && ok) {
+              const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res2) + (long)m * p.res2_ld + n);
+              v[h][0] += q.x; v[h][1] += q.y; v[h][2] += q.z; v[h][3] += q.w;
             }
-            if (p.out_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + y_base + (long)m * p.y_ld + n) = make_float4(v[0], v[1], v[2], v[3]);
-            else store_split3(reinterpret_cast<bf16_t*>(p.y) + split3_at(m, n, p.y_ld, (p.korder & 8) ? M : 0), p.y_bstride, v);
+            if (p.out_f32) {
+              if (ok) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + y_base + (long)m * p.y_ld + n) = make_float4(v[h][0], v[h][1], v[h][2], v[h][3]);
+            } else if (!(p.korder & 8)) {
+              if (ok) store_split3(reinterpret_cast<bf16_t*>(p.y) + split3_at(m, n, p.y_ld, 0), p.y_bstride, v[h]);
+            } else {
+              uint32_t h0, m0, h1, mm1;
+              split3_pair(v[h][0], v[h][1], h0, m0, lw[h][0]);
+              split3_pair(v[h][2], v[h][3], h1, mm1, lw[h][1]);
+              // (every lane executes the swaps; only the stores are guarded)
+              const auto s0 = __builtin_amdgcn_permlane16_swap(h0, m0, false, false);
+              const auto s1 = __builtin_amdgcn_permlane16_swap(h1, mm1, false, false);
+              if (ok) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.y) + split3_at(m, ne, p.y_ld, M) + (oddg ? p.y_bstride : 0)) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            }
+          }
+          if (!p.out_f32 && (p.korder & 8)) {
+            const auto t0 = __builtin_amdgcn_permlane16_swap(lw[0][0], lw[1][0], false, false);
+            const auto t1 = __builtin_amdgcn_permlane16_swap(lw[0][1], lw[1][1], false, false);
+            const int ml = m1 + (oddg ? 8 : 0);
+            if (nok && ml < M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.y) + split3_at(ml, ne, p.y_ld, M) + 2 * p.y_bstride) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
           }
         }
-        acc[fn][fm] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
     epi_pending = false;

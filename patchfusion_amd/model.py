@@ -214,12 +214,46 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
 
     def load_state_dict(self, *a, **k):
         self._engine = None
+        if getattr(self, "_params_freed", False):             # re-materialise the parameter storage that free_parameters() released
+            dev = self._device
+            for name, e in self.spec.items():
+                mod = self
+                parts = name.split('.')
+                for q in parts[:-1]:
+                    mod = mod._modules[q]
+                t = mod._parameters.get(parts[-1])
+                t = t if t is not None else mod._buffers[parts[-1]]
+                t.data = torch.zeros(e.shape, dtype=e.dtype, device=dev)
+            self._params_freed = False
         return super().load_state_dict(*a, **k)
 
     def _apply(self, fn, *a, **k):
+        if getattr(self, "_params_freed", False):
+            raise RuntimeError("PatchFusion.free_parameters() released the unpacked checkpoint tensors; the module cannot be moved / cast "
+                               "(that rebuilds the engine from them).  load_state_dict() the checkpoint again first.")
         self._engine = None
         self._forget_engine_state(release=True)
         return super()._apply(fn, *a, **k)
+
+    def free_parameters(self):
+        """OPT-IN memory saver for inference deployments (round-4 review item 7a): once the engine is built, every layer lives in its packed form
+        (f32 GEMM layout, split-precision planes, Winograd filters) and the unpacked nn.Parameter / buffer tensors of the two checkpoints are dead
+        weight on the device (~3.4 GB for ViT-L; 8x replicated at N = 8).  This builds the engine if needed and releases their storage.  Afterwards
+        ``state_dict()`` / ``get_save_dict()`` / ``.to()`` raise (the packed form is not a checkpoint format); ``load_state_dict(sd)`` brings the
+        module back to the normal state.  Nothing else changes: forward results are bit-identical."""
+        self._ensure_engine()
+        for mod in self.modules():
+            for t in list(mod._parameters.values()) + list(mod._buffers.values()):
+                if t is not None:
+                    t.data = torch.empty(0, dtype=t.dtype, device=t.device)
+        self._params_freed = True
+        return self
+
+    def state_dict(self, *a, **k):
+        if getattr(self, "_params_freed", False):
+            raise RuntimeError("PatchFusion.free_parameters() released the unpacked checkpoint tensors: there is no state_dict to return "
+                               "(load_state_dict() the checkpoint again to restore them)")
+        return super().state_dict(*a, **k)
 
     def _forget_engine_state(self, release=False):
         """library-side state tied to an engine: the cached PF_* switches and per-layer dispatch plans of hip_ops (they reference the packed layers
@@ -268,6 +302,8 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
     def _ensure_engine(self):
         if self._engine is None:
             from .engine import BranchNet, ExternalCoreBranchNet, FusionNet, G2LNet
+            if getattr(self, "_params_freed", False):
+                raise RuntimeError("the engine has to be rebuilt but free_parameters() released the checkpoint tensors: load_state_dict() first")
             sd = self.state_dict()
             dev = next(iter(sd.values())).device
             if self._ops is None and dev.type != "cuda":

@@ -112,6 +112,49 @@ def conv_winograd(dt):
     return max(errs), 8e-6, "winograd F(2,3) / F(4,3) vs direct f32"
 
 
+def conv_winograd_subbatch(dt):
+    """three-step split-precision Winograd layers under the workspace cap (hip_ops `wino3s`: PF_WS_CAP_GB makes a layer run as sub-batches of its
+    images through one smaller arena pair) and under the measured scheduling switches of csrc/winograd.hip run_split3 (resident transforms
+    PF_W3_TGRID, capped GEMM grid PF_W3_GRID, GEMM token PF_W3_TOKEN): every variant BIT-IDENTICAL to the plain launch (no op mixes images, the
+    switches move work between CUs only), incl. channel-slice views and both residuals."""
+    import os
+    keys = ("PF_WINOGRAD", "PF_WINOGRAD_MIN_PIXELS", "PF_WINO_FUSED", "PF_WS_CAP_GB", "PF_W3_TGRID", "PF_W3_GRID", "PF_W3_TOKEN")
+    old = {k: os.environ.get(k) for k in keys}
+    worst = 0.0
+    try:
+        os.environ.update(PF_WINOGRAD="4", PF_WINOGRAD_MIN_PIXELS="0", PF_WINO_FUSED="0")
+        for i, (B, H, W, cin, cout, kw) in enumerate(((4, 37, 41, 256, 256, dict(act="relu", res=True, res2=True)),
+                                                      (6, 18, 23, 544, 320, dict(relu_in=True)),
+                                                      (8, 56, 74, 256, 256, dict(act="relu")))):
+            g = torch.Generator().manual_seed(700 + i)
+            w = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+            pw = pk.pack_conv(w, torch.randn(cout, generator=g), dtype=torch.float32).to(DEV)
+            assert pw.wino_u3 is not None
+            x = _rand((B, H, W, cin + 16), torch.float32, 710 + i)[..., 8:8 + cin]
+            r1 = _rand((B, H, W, cout), torch.float32, 720 + i) if kw.get("res") else None
+            r2 = _rand((B, H, W, cout + 8), torch.float32, 730 + i)[..., :cout] if kw.get("res2") else None
+            outs = []
+            for env in (dict(), dict(PF_WS_CAP_GB="0.004"), dict(PF_WS_CAP_GB="0.0005"), dict(PF_W3_TGRID="8", PF_W3_GRID="64", PF_W3_TOKEN="1")):
+                for k in keys[3:]:
+                    os.environ.pop(k, None)
+                os.environ.update(env)
+                _switches_changed()
+                yb = torch.zeros((B, H, W, cout + 16), dtype=torch.float32, device=DEV)
+                hip().conv(x, pw, yb[..., 8:8 + cout], pad=1, act=kw.get("act"), relu_in=kw.get("relu_in", False), res=r1, res2=r2)
+                outs.append(yb)
+            for o in outs[1:]:
+                worst = max(worst, float((o - outs[0]).abs().max()))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        _switches_changed()
+    torch.cuda.synchronize()
+    return worst, 0.0, "three-step Winograd: sub-batched / resident / capped / token-chained == plain launch, bit for bit"
+
+
 def conv_winograd_fused(dt):
     """fused float32 Winograd F(4x4,3x3) (csrc/wino_fused.hip: LDS-DMA halo -> in-kernel B^T d B -> 36-plane MFMA -> in-kernel A^T M A +
     epilogue) against the DIRECT float32 convolution, and against the three-step path it replaces.  Cases: partial tiles in both
@@ -882,7 +925,7 @@ CHECKS = {
     "conv_gemm_vitl_linear_shape": conv_gemm_vitl_linear_shape, "conv_bf16_pp": conv_bf16_pp, "conv_dominant_launch": conv_dominant_launch,
     "conv_transpose": conv_transpose, "patch_embed_tokens": patch_embed_tokens, "layernorm": layernorm,
     "vit_attention": vit_attention, "vit_attention_split": vit_attention_split, "gemm_split3": gemm_split3, "gemm_split3_persist": gemm_split3_persist, "vit_attention_split3": vit_attention_split3, "swin_ops": swin_ops, "resize_ops": resize_ops, "roi_ops": roi_ops,
-    "conv_winograd": conv_winograd, "conv_winograd_fused": conv_winograd_fused, "misc_ops": misc_ops, "bins_ops": bins_ops, "bins_tail": bins_tail, "stitch_ops": stitch_ops,
+    "conv_winograd": conv_winograd, "conv_winograd_subbatch": conv_winograd_subbatch, "conv_winograd_fused": conv_winograd_fused, "misc_ops": misc_ops, "bins_ops": bins_ops, "bins_tail": bins_tail, "stitch_ops": stitch_ops,
 }
-F32_ONLY = {"bins_ops", "bins_tail", "stitch_ops", "conv_winograd", "conv_winograd_fused", "vit_attention_split", "gemm_split3", "gemm_split3_persist", "vit_attention_split3"}
+F32_ONLY = {"bins_ops", "bins_tail", "stitch_ops", "conv_winograd", "conv_winograd_subbatch", "conv_winograd_fused", "vit_attention_split", "gemm_split3", "gemm_split3_persist", "vit_attention_split3"}
 DTYPES = {"fp32": torch.float32, "bf16": torch.bfloat16}

@@ -34,7 +34,14 @@ def main():
     if not rows:
         print("no rows for", sub)
         return
-    CALLS = 6
+    CALLS = int(os.environ.get("PF_PMC_CALLS", "6"))      # pf_conv / pf_gemm_split3 calls of one `bench.py --roofline-only` run (the bench prints "calls": n)
+    for d in sys.argv[4:]:                                 # ... or read it from the run's own JSON line (log beside the pass directory)
+        try:
+            for ln in open(d + ".log"):
+                if ln.startswith("{") and '"calls"' in ln:
+                    CALLS = int(json.loads(ln)["calls"])
+        except Exception:
+            pass
     name = sorted({r["Kernel_Name"] for r in rows}, key=len)[0]
     seen = defaultdict(set)
     tot = defaultdict(float)
@@ -78,7 +85,7 @@ def main():
         sys.path.insert(0, ROOT)
         from patchfusion_amd.packing import winograd_mode
         wm = winograd_mode()
-    j = {"kernel": name, "grid": grid, "dtype": dtype, "kernel_source_sha": h.hexdigest()[:12], "winograd_m": wm, "dispatches_total_all_passes": len(durs), "pf_conv_calls_per_pass": 6,
+    j = {"kernel": name, "grid": grid, "dtype": dtype, "kernel_source_sha": h.hexdigest()[:12], "winograd_m": wm, "ws_cap_gb": os.environ.get("PF_WS_CAP_GB", "2.5"), "dispatches_total_all_passes": len(durs), "pf_conv_calls_per_pass": CALLS,
          "command": "rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python bench.py --roofline-only --dtype " + dtype,
          "per_launch": per, "derived": der}
     json.dump(j, open(out, "w"), indent=1)

@@ -377,11 +377,11 @@ def roofline(dtype, dev, gemm_only=False):
         # points -> output transform.  Dominant launch = that GEMM (round 4: gemm_split3_persist192_kernel, v_mfma_f32_16x16x32_bf16 x 6 per useful product):
         # priced as its USEFUL float32 multiply-adds 36 * 2 * T * C * C against the f32 MFMA peak -- the roofline of the arithmetic the layer
         # asks for -- with the executed bf16 rate against the bf16 peak beside it.
-        # (round 5: the engine runs a layer whose V + M arenas exceed PF_WS_CAP_GB as sub-batches of its images, hip_ops.wino3_subbatches -- the launch
-        # timed here is the launch the pass issues: Bs = B / ns images per launch, ns launches per layer call)
-        ns = hip_ops.wino3_subbatches(B, H, W, pw)[0]
-        Bs = B // ns
-        T = Bs * -(-H // 4) * -(-W // 4)
+        # (round 5: the engine walks a layer whose V + M arenas would exceed PF_WS_CAP_GB in windows of its Winograd tiles, hip_ops.wino3_window -- the launch
+        # timed here is the launch the pass issues: `window` tiles per launch, ns launches per layer call)
+        T, ns = hip_ops.wino3_window(B, H, W, pw)[:2]
+        Tall = B * -(-H // 4) * -(-W // 4)
+        T = min(T, Tall)
         V3 = torch.randn(3, 36, C // 32, T, 32, device=dev).to(torch.bfloat16)       # chunk-major planes, as the input transform writes them
         Mw = torch.empty(36 * T * C, device=dev)
         iters = 5 * ns                    # (the same ~50 ms of launches whatever the sub-batch: a 13 ms window of short launches reads ~10 % slow -- clock ramp)
@@ -406,8 +406,8 @@ def roofline(dtype, dev, gemm_only=False):
         peak = PEAK_TFLOPS["bf16"] / 6.0
         return {"bound": "mfma",
                 "kernel": f"gemm_split3_persist192_kernel (persistent 192 x 192 tiles, 6 x v_mfma_f32_16x16x32_bf16 per float32 product, f32 accumulation) as the batched transform-domain GEMM of the "
-                          f"largest layer: 36 planes x [{T} x {C}].[{C} x {C}] = 3x3 {C}->{C} @ {Bs}x{H}x{W} (GuidedFusion up-conv under Winograd F(4x4,3x3); the layer call over "
-                          f"{B} tiles issues {ns} such launches: workspace cap PF_WS_CAP_GB)",
+                          f"largest layer: 36 planes x [{T} x {C}].[{C} x {C}] = a window of {T} of the {Tall} Winograd tiles of 3x3 {C}->{C} @ {B}x{H}x{W} (GuidedFusion up-conv under F(4x4,3x3); "
+                          f"the layer call issues {ns} such launches: workspace cap PF_WS_CAP_GB)",
                 "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 # the dense bf16 MFMA rate this chip SUSTAINS on random operands, measured with a register-resident stream (tools/mfma_ceiling.hip,
                 # profiles/r5_mfma_ceiling.md: 2020 TF/s at 2.05 GHz with the h / m / l operand pattern; zeros 2467 at 2.39 GHz) -- the practical ceiling beside the
@@ -419,7 +419,7 @@ def roofline(dtype, dev, gemm_only=False):
                 "vs_f32_mfma_peak": round(ach / PEAK_TFLOPS["fp32"], 4),
                 "executed_bf16": {"tflops": round(6 * ach, 1), "peak": PEAK_TFLOPS["bf16"], "frac": round(6 * ach / PEAK_TFLOPS["bf16"], 4)},
                 "layer": None if ms_layer is None else {
-                    "what": f"whole layer = input transform (split planes) + batched GEMM + output transform/epilogue, 3x3 {C}->{C} @ {B}x{H}x{W} ({ns} sub-batches)",
+                    "what": f"whole layer = input transform (split planes) + batched GEMM + output transform/epilogue, 3x3 {C}->{C} @ {B}x{H}x{W} ({ns} tile windows)",
                     "ms": round(ms_layer, 4), "transforms_ms": round(ms_layer - ns * ms, 4), "direct_conv_flops": direct_flops,
                     "direct_conv_tflops_equivalent": round(direct_flops / (ms_layer * 1e-3) / 1e12, 2)}}
     if pw.wino_up is not None and pk.winograd_applies(pw, B * H * W, 1, 1, "relu") and hip_ops._fused_wanted(B, H, W, pw):

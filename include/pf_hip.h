@@ -78,6 +78,10 @@ int pf_conv_winograd(const pf_conv_params* p, int m, const void* U, int u_rows, 
  * (patchfusion_amd/packing.py PackedConv.wino_u3; u_kpad must equal Cin), M = 36 x T x Cout float32; one batched pf_gemm_split3 launch
  * (korder = 6) between the transforms. */
 int pf_conv_winograd_split3(const pf_conv_params* p, const void* U3, int u_rows, int u_kpad, void* V3, void* M, void* stream);
+/* the same layer `window` Winograd tiles at a time (window % 8 == 0; 0 = all tiles at once): V3 / M then are arenas for ONE window (3 x 36 x window x Cin
+ * bf16, 36 x window x Cout float32) that every window reuses -- small windows keep the pair inside the 256 MB memory-side cache.  Tiles are independent:
+ * identical results for every window. */
+int pf_conv_winograd_split3_windowed(const pf_conv_params* p, const void* U3, int u_rows, int u_kpad, void* V3, void* M, long window, void* stream);
 
 /* FUSED Winograd F(4x4, 3x3) (csrc/wino_fused.hip): the same layers in ONE kernel -- the transformed input and the transform-domain
  * products never exist in HBM.  `p` as for pf_conv_winograd (p->w is not read); `up` = the filters in MFMA fragment order

@@ -56,6 +56,7 @@ SIGNATURES = {
     "pf_nhwc_to_nchw_f32": [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp],
     "pf_conv_winograd": [C.POINTER(ConvParams), ci, vp, ci, ci, vp, vp, vp],
     "pf_conv_winograd_split3": [C.POINTER(ConvParams), vp, ci, ci, vp, vp, vp],
+    "pf_conv_winograd_split3_windowed": [C.POINTER(ConvParams), vp, ci, ci, vp, vp, C.c_long, vp],
     "pf_gemm_split3": [C.POINTER(ConvParams), vp],
     "pf_gemm_split3_ex": [C.POINTER(ConvParams), ci, vp],
     "pf_gemm_split3_timed": [C.POINTER(ConvParams), ci, C.POINTER(cf), vp],

@@ -67,10 +67,11 @@ template <> struct Wino<4> {
 // 3x slower -- ~16 B/clk/CU of store issue -- which is why the transforms cannot hide on a CU subset beside the GEMM, profiles/r5_overlap_probe_resident.md.)
 template <int MT, bool SPLIT = false>
 __global__ __launch_bounds__(512) void wino_input_kernel(const float* __restrict__ x, int x_ld, int B, int H, int W, int C, int relu_in,
-                                                         float* __restrict__ V, int TH, int TW, long total) {
+                                                         float* __restrict__ V, int TH, int TW, long total, long tile0, long T) {
+  // (tile window, round 5: this launch transforms tiles [tile0, tile0 + T) of the layer's B * TH * TW tiles into a V of T rows -- run_split3 walks a
+  // layer in windows small enough for the arena pair to stay in the 256 MB memory-side cache)
   constexpr int A = MT + 2;
   const int cv = C >> 2;
-  const long T = (long)B * TH * TW;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
   int c4;
   long tile;
@@ -85,7 +86,8 @@ __global__ __launch_bounds__(512) void wino_input_kernel(const float* __restrict
     c4 = (int)(idx % cv);
     tile = idx / cv;
   }
-  const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((long)TW * TH));
+  const long gt = tile + tile0;                       // position of the tile in the layer
+  const int tx = (int)(gt % TW), ty = (int)((gt / TW) % TH), b = (int)(gt / ((long)TW * TH));
   float d[A][A][4];
 #pragma unroll
   for (int i = 0; i < A; ++i) {
@@ -145,14 +147,14 @@ template <int MT>
 __global__ __launch_bounds__(512) void wino_output_kernel(const float* __restrict__ M, int N, const float* __restrict__ bias, int relu,
                                                           const float* __restrict__ res, int res_ld, const float* __restrict__ res2,
                                                           int res2_ld, float* __restrict__ y, int y_ld, int B, int H, int W, int TH,
-                                                          int TW) {
+                                                          int TW, long tile0, long T) {
   constexpr int A = MT + 2;
   const int nv = N >> 2;
-  const long T = (long)B * TH * TW;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < T * nv; idx += (long)gridDim.x * blockDim.x) {      // (grid-stride: see wino_input_kernel)
   const int n4 = (int)(idx % nv);
   const long tile = idx / nv;
-  const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((long)TW * TH));
+  const long gt = tile + tile0;
+  const int tx = (int)(gt % TW), ty = (int)((gt / TW) % TH), b = (int)(gt / ((long)TW * TH));
   const size_t plane = (size_t)T * N;
   const float* m = M + (size_t)tile * N + n4 * 4;
   float t[MT][A][4];                                  // A^T m : along the rows
@@ -222,7 +224,7 @@ int run(const pf_conv_params* p, const float* U, int u_rows, int u_kpad, float* 
   if (T > 0x7fffffffL) return PF_ERR_ARG;
   const long nin = T * (p->Cin / 4), nout = T * (p->Cout / 4);
   hipLaunchKernelGGL(wino_input_kernel<MT>, dim3((unsigned)((nin + 255) / 256)), dim3(256), 0, st, static_cast<const float*>(p->x), p->x_ld,
-                     p->B, p->H, p->W, p->Cin, p->relu_in, V, TH, TW, nin);
+                     p->B, p->H, p->W, p->Cin, p->relu_in, V, TH, TW, nin, 0L, T);
   if (launch_ok() != PF_OK) return PF_ERR_LAUNCH;
   pf_conv_params q = {};
   q.x_ld = p->Cin; q.B = 1; q.H = 1; q.W = (int)T; q.Cin = p->Cin;
@@ -236,7 +238,7 @@ int run(const pf_conv_params* p, const float* U, int u_rows, int u_kpad, float* 
   if (rc != PF_OK) return rc;
   hipLaunchKernelGGL(wino_output_kernel<MT>, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, M, p->Cout, p->bias,
                      p->act == PF_ACT_RELU ? 1 : 0, static_cast<const float*>(p->res), p->res_ld, static_cast<const float*>(p->res2),
-                     p->res2_ld, static_cast<float*>(p->y), p->y_ld, p->B, p->H, p->W, TH, TW);
+                     p->res2_ld, static_cast<float*>(p->y), p->y_ld, p->B, p->H, p->W, TH, TW, 0L, T);
   return launch_ok();
 }
 
@@ -252,46 +254,53 @@ hipEvent_t gemm_token() {
 
 // F(4x4,3x3) with the transform-domain GEMM in split precision: V is written as three bf16 planes, U3 = the three planes of G g G^T
 // (chunk-major [3][36][Cin/32][u_rows][32] bf16 = PackedConv.wino_u3, the split3 of packing.winograd_filters), ONE batched pf_gemm_split3 launch (plane = blockIdx.y), M float32.
-int run_split3(const pf_conv_params* p, const void* U3, int u_rows, int u_kpad, void* V3, float* M, hipStream_t st) {
+int run_split3(const pf_conv_params* p, const void* U3, int u_rows, int u_kpad, void* V3, float* M, long window, hipStream_t st) {
   constexpr int MT = 4, A = 6;
   const int TH = (p->H + MT - 1) / MT, TW = (p->W + MT - 1) / MT;
-  const long T = (long)p->B * TH * TW;
-  if (T > 0x7fffffffL) return PF_ERR_ARG;
-  const long nin = ((T + 7) / 8) * 8 * (p->Cin / 4), nout = T * (p->Cout / 4);       // (input transform: whole tile octets, see the kernel)
+  const long Tall = (long)p->B * TH * TW;
+  if (Tall > 0x7fffffffL) return PF_ERR_ARG;
+  if (window <= 0 || window > Tall) window = Tall;
   // PF_W3_TGRID = n > 0: the transforms run RESIDENT on n CUs (n blocks of 512 threads walking the items) instead of flooding the chip
   int tgrid = 0;
   if (const char* s = getenv("PF_W3_TGRID")) tgrid = atoi(s);
-  const bool resident = tgrid > 0 && nin > (long)tgrid * 512 * 4;
-  const dim3 gin = resident ? dim3((unsigned)tgrid) : dim3((unsigned)((nin + 255) / 256)), bin = resident ? dim3(512) : dim3(256);
-  hipLaunchKernelGGL((wino_input_kernel<MT, true>), gin, bin, 0, st, static_cast<const float*>(p->x), p->x_ld,
-                     p->B, p->H, p->W, p->Cin, p->relu_in, static_cast<float*>(V3), TH, TW, nin);
-  if (launch_ok() != PF_OK) return PF_ERR_LAUNCH;
-  pf_conv_params q = {};
-  q.x_ld = p->Cin; q.B = 1; q.H = 1; q.W = (int)T; q.Cin = p->Cin;
-  q.w_rows = u_rows; q.Kpad = u_kpad;
-  q.y_ld = p->Cout; q.OH = 1; q.OW = (int)T; q.Cout = p->Cout;
-  q.KH = q.KW = 1; q.stride = 1; q.pad = 0; q.act = PF_ACT_NONE; q.shuffle = 1; q.dtype = PF_DTYPE_BF16; q.out_f32 = 1;
-  q.x = V3; q.w = U3; q.y = M;
-  q.korder = 6;                                         // V3 and U3 are chunk-major: [plane][point][Cin/32][rows][32]
-  q.batch = A * A;                                      // transform points: x / w / y advance by one [T][Cin] / [rows][Kpad] / [T][Cout] block each
-  q.x_bstride = (long)A * A * T * p->Cin;               // h / m / l plane strides
-  q.w_bstride = (long)A * A * u_rows * u_kpad;
-  // Overlap of the HBM-bound transforms of one tile batch with the matrix-bound GEMM of the other (two streams): the persistent GEMM
-  // leaves CUs free (PF_W3_GRID blocks instead of one per CU) and, with PF_W3_TOKEN=1, the big GEMMs of ALL streams are chained through one event in
-  // host-issue order, so that two capped GEMMs never compete for the same CUs while the transforms of the waiting stream fill the free ones.
+  // Overlap of the HBM-bound transforms of one tile batch with the matrix-bound GEMM of the other (two streams; measured, off): the
+  // persistent GEMM leaves CUs free (PF_W3_GRID blocks instead of one per CU) and, with PF_W3_TOKEN=1, the big GEMMs of ALL streams are chained
+  // through one event in host-issue order, so that two capped GEMMs never compete for the same CUs.
   int cap = 0;
   if (const char* s = getenv("PF_W3_GRID")) cap = atoi(s);
   hipEvent_t tok = nullptr;
   if (const char* s = getenv("PF_W3_TOKEN")) if (s[0] == '1') tok = gemm_token();
-  if (tok) hipStreamWaitEvent(st, tok, 0);
-  const int rc = pf_gemm_split3_ex(&q, cap, st);
-  if (rc != PF_OK) return rc;
-  if (tok) hipEventRecord(tok, st);
-  const bool resident_out = tgrid > 0 && nout > (long)tgrid * 512 * 4;
-  hipLaunchKernelGGL(wino_output_kernel<MT>, resident_out ? dim3((unsigned)tgrid) : dim3((unsigned)((nout + 255) / 256)), resident_out ? dim3(512) : dim3(256), 0, st, M, p->Cout, p->bias,
-                     p->act == PF_ACT_RELU ? 1 : 0, static_cast<const float*>(p->res), p->res_ld, static_cast<const float*>(p->res2),
-                     p->res2_ld, static_cast<float*>(p->y), p->y_ld, p->B, p->H, p->W, TH, TW);
-  return launch_ok();
+  // TILE WINDOWS (round 5): the layer's tiles go through the three steps `window` tiles at a time, all windows through the SAME V / M arena -- launches
+  // of one stream are ordered.  Winograd tiles are independent, so the numbers do not depend on the window.
+  for (long t0 = 0; t0 < Tall; t0 += window) {
+    const long T = Tall - t0 < window ? Tall - t0 : window;
+    const long nin = ((T + 7) / 8) * 8 * (p->Cin / 4), nout = T * (p->Cout / 4);       // (input transform: whole tile octets, see the kernel)
+    const bool resident = tgrid > 0 && nin > (long)tgrid * 512 * 4;
+    const dim3 gin = resident ? dim3((unsigned)tgrid) : dim3((unsigned)((nin + 255) / 256)), bin = resident ? dim3(512) : dim3(256);
+    hipLaunchKernelGGL((wino_input_kernel<MT, true>), gin, bin, 0, st, static_cast<const float*>(p->x), p->x_ld,
+                       p->B, p->H, p->W, p->Cin, p->relu_in, static_cast<float*>(V3), TH, TW, nin, t0, T);
+    if (launch_ok() != PF_OK) return PF_ERR_LAUNCH;
+    pf_conv_params q = {};
+    q.x_ld = p->Cin; q.B = 1; q.H = 1; q.W = (int)T; q.Cin = p->Cin;
+    q.w_rows = u_rows; q.Kpad = u_kpad;
+    q.y_ld = p->Cout; q.OH = 1; q.OW = (int)T; q.Cout = p->Cout;
+    q.KH = q.KW = 1; q.stride = 1; q.pad = 0; q.act = PF_ACT_NONE; q.shuffle = 1; q.dtype = PF_DTYPE_BF16; q.out_f32 = 1;
+    q.x = V3; q.w = U3; q.y = M;
+    q.korder = 6;                                         // V3 and U3 are chunk-major: [plane][point][Cin/32][rows][32]
+    q.batch = A * A;                                      // transform points: x / w / y advance by one [T][Cin] / [rows][Kpad] / [T][Cout] block each
+    q.x_bstride = (long)A * A * T * p->Cin;               // h / m / l plane strides
+    q.w_bstride = (long)A * A * u_rows * u_kpad;
+    if (tok) hipStreamWaitEvent(st, tok, 0);
+    const int rc = pf_gemm_split3_ex(&q, cap, st);
+    if (rc != PF_OK) return rc;
+    if (tok) hipEventRecord(tok, st);
+    const bool resident_out = tgrid > 0 && nout > (long)tgrid * 512 * 4;
+    hipLaunchKernelGGL(wino_output_kernel<MT>, resident_out ? dim3((unsigned)tgrid) : dim3((unsigned)((nout + 255) / 256)), resident_out ? dim3(512) : dim3(256), 0, st, M,
+                       p->Cout, p->bias, p->act == PF_ACT_RELU ? 1 : 0, static_cast<const float*>(p->res), p->res_ld, static_cast<const float*>(p->res2),
+                       p->res2_ld, static_cast<float*>(p->y), p->y_ld, p->B, p->H, p->W, TH, TW, t0, T);
+    if (launch_ok() != PF_OK) return PF_ERR_LAUNCH;
+  }
+  return PF_OK;
 }
 
 }  // namespace
@@ -302,7 +311,18 @@ extern "C" int pf_conv_winograd_split3(const pf_conv_params* p, const void* U3, 
   if (p->OH != p->H || p->OW != p->W || p->Cin % 32 || p->Cout % 8 || p->Cin <= 0 || p->Cout <= 0) return PF_ERR_ARG;
   if (p->act != PF_ACT_NONE && p->act != PF_ACT_RELU) return PF_ERR_ARG;
   if (u_rows < p->Cout || u_kpad != p->Cin) return PF_ERR_ARG;       // (chunk-major planes are dense in K)
-  return run_split3(p, U3, u_rows, u_kpad, V3, static_cast<float*>(M), ST(stream));
+  return run_split3(p, U3, u_rows, u_kpad, V3, static_cast<float*>(M), 0, ST(stream));
+}
+
+// the same layer `window` Winograd tiles at a time (0 / >= all tiles: one window): V3 / M are arenas for ONE window -- 3 x 36 x ceil8(window) x Cin bf16
+// and 36 x window x Cout float32.  Identical results for every window (tiles are independent).
+extern "C" int pf_conv_winograd_split3_windowed(const pf_conv_params* p, const void* U3, int u_rows, int u_kpad, void* V3, void* M, long window, void* stream) {
+  if (!p || !U3 || !V3 || !M || !p->x || !p->y || window < 0 || (window > 0 && window % 8)) return PF_ERR_ARG;
+  if (p->dtype != PF_DTYPE_F32 || p->KH != 3 || p->KW != 3 || p->stride != 1 || p->pad != 1 || p->shuffle > 1 || p->scale) return PF_ERR_ARG;
+  if (p->OH != p->H || p->OW != p->W || p->Cin % 32 || p->Cout % 8 || p->Cin <= 0 || p->Cout <= 0) return PF_ERR_ARG;
+  if (p->act != PF_ACT_NONE && p->act != PF_ACT_RELU) return PF_ERR_ARG;
+  if (u_rows < p->Cout || u_kpad != p->Cin) return PF_ERR_ARG;
+  return run_split3(p, U3, u_rows, u_kpad, V3, static_cast<float*>(M), window, ST(stream));
 }
 
 extern "C" int pf_conv_winograd(const pf_conv_params* p, int m, const void* U, int u_rows, int u_kpad, void* V, void* M, void* stream) {

@@ -168,23 +168,22 @@ def _fused_group():
             | (int(_env("PF_WINO_DBG", "0")) << 20))     # PF_WINO_DBG: timing decomposition only (wrong results), see wino_fused.hip
 
 
-def wino3_subbatches(B, H, W, pw):
-    """(ns, nV, nM): a three-step split-precision Winograd layer over B images runs as `ns` sub-batches of B / ns images through ONE arena pair of
-    nV + nM float32 words (V: three bf16 planes of whole tile octets; M: float32).  PF_WS_CAP_GB (default 2.5): the largest V + M pair a layer may ask
-    for -- no op mixes images, so the numbers are identical; the headline layer (544->544 @ 8 x 392 x 518: 11.9 + 8.0 GB per stream un-split) runs tile by
-    tile on 2.3 GB.  Measured (profiles/r5_ws_cap.md, r5_subbatch_probe.md): the batched GEMM keeps its rate (0.555 of 2500/6 at 8 tiles per launch, 0.551 at
-    2, 0.538 at 1), the layer alone is unchanged (14.2-14.8 ms), and the IMAGE pass gets faster -- 188.6 ms uncapped, 187.3 at 5 GB, 186.4 at 2.5 GB, 187.0 at
-    1.3 GB: the two tile streams interleave at a finer grain -- while the peak allocation falls from 62.8 to 36 GiB."""
-    a2 = 36
-
-    def need(b):
-        t = b * -(-H // 4) * -(-W // 4)
-        return (a2 * (-(-t // 8) * 8) * pw.cin * 3 + 1) // 2, a2 * t * pw.cout
+def wino3_window(B, H, W, pw):
+    """(window, nwin, nV, nM): a three-step split-precision Winograd layer over T = B ceil(H/4) ceil(W/4) tiles runs `window` tiles at a time (nwin
+    windows, the last one ragged) through ONE arena pair of nV + nM float32 words (V: three bf16 planes; M: float32) -- csrc/winograd.hip run_split3.
+    Winograd tiles are independent, so the numbers are identical for every window.  PF_WS_CAP_GB (default 2.5) is the largest V + M pair a layer may ask
+    for; windows are multiples of 192 tiles (the GEMM's token tile).  The headline layer (544->544 @ 8 x 392 x 518: 11.9 + 8.0 GB per stream in one piece)
+    runs in 8 windows of 2.3 GB.  Measured (profiles/r5_ws_cap.md, r5_subbatch_probe.md): the batched GEMM keeps its rate (0.555 of 2500/6 at 8 tiles of
+    392 x 518 per launch, 0.551 at 2, 0.538 at 1), and the IMAGE pass gets faster -- 188.6 ms in one piece, 187.3 at 5 GB, 186.4 at 2.5 GB: the two tile
+    streams interleave at a finer grain -- while the peak allocation falls from 62.8 to 31 GiB."""
+    T = B * -(-H // 4) * -(-W // 4)
+    per_tile = 36 * (pw.cin * 6 + pw.cout * 4)
     cap = float(_env("PF_WS_CAP_GB", "2.5")) * 2 ** 30
-    ns = 1
-    while ns < B and (B % ns or sum(need(B // ns)) * 4 > cap):
-        ns += 1
-    return (ns,) + need(B // ns)
+    window = max(int(cap // per_tile) // 192 * 192, 192)
+    if window >= T:
+        window = -(-T // 8) * 8
+    nwin = -(-T // window)
+    return window, nwin, (36 * window * pw.cin * 3 + 1) // 2, 36 * window * pw.cout
 
 
 class HipOps:
@@ -248,19 +247,8 @@ class HipOps:
             assert f32_io
             if m == 4 and _split3_three_step(pw):
                 # (split: V holds three bf16 planes = 6 bytes per element instead of 4; whole tile octets, csrc/winograd.hip)
-                ns, nV, nM = wino3_subbatches(B, H, W, pw)
-                ex = (_p(pw.wino_u3), pw.wino_u3.shape[3], pw.wino_u3.shape[2] * 32, nV, nM)
-                if ns == 1:
-                    return "wino3", p, ex
-                bs = B // ns
-                subs = []
-                for k in range(ns):                       # sub-batch k: the same filled parameter block with B = bs and offset data pointers
-                    q = ConvParams()
-                    C.memmove(C.byref(q), C.byref(p), C.sizeof(ConvParams))
-                    q.B = bs
-                    subs.append((q, k * bs * H * W * p.x_ld * 4, k * bs * OH * OW * p.y_ld * 4,
-                                 k * bs * OH * OW * p.res_ld * 4, k * bs * OH * OW * p.res2_ld * 4))
-                return "wino3s", p, ex + (subs,)
+                window, _, nV, nM = wino3_window(B, H, W, pw)
+                return "wino3", p, (_p(pw.wino_u3), pw.wino_u3.shape[3], pw.wino_u3.shape[2] * 32, nV, nM, window)
             return "wino", p, (m, _p(pw.wino_u), pw.wino_u.shape[1], pw.wino_u.shape[2], a2 * T * pw.cin, a2 * T * pw.cout)
         return "direct", p, None          # (incl. fused-only layers below the block threshold)
 
@@ -272,18 +260,8 @@ class HipOps:
             check(_L.pf_conv_winograd_fused(C.byref(p), extra[0], extra[1], extra[2], _stream()), "pf_conv_winograd_fused")
         elif route == "wino3":
             V, Mw = _workspace(device, extra[3], extra[4])
-            check(_L.pf_conv_winograd_split3(C.byref(p), extra[0], extra[1], extra[2], C.c_void_p(V.data_ptr()), C.c_void_p(Mw.data_ptr()), _stream()),
-                  "pf_conv_winograd_split3")
-        elif route == "wino3s":
-            V, Mw = _workspace(device, extra[3], extra[4])
-            vp, mp, st = C.c_void_p(V.data_ptr()), C.c_void_p(Mw.data_ptr()), _stream()
-            for q, xo, yo, ro, r2o in extra[5]:           # launches of one stream are ordered: the sub-batches reuse the one arena pair
-                q.x, q.y = p.x + xo, p.y + yo
-                if p.res:
-                    q.res = p.res + ro
-                if p.res2:
-                    q.res2 = p.res2 + r2o
-                check(_L.pf_conv_winograd_split3(C.byref(q), extra[0], extra[1], extra[2], vp, mp, st), "pf_conv_winograd_split3")
+            check(_L.pf_conv_winograd_split3_windowed(C.byref(p), extra[0], extra[1], extra[2], C.c_void_p(V.data_ptr()), C.c_void_p(Mw.data_ptr()),
+                                                      extra[5], _stream()), "pf_conv_winograd_split3_windowed")
         elif route == "wino":
             V, Mw = _workspace(device, extra[4], extra[5])
             check(_L.pf_conv_winograd(C.byref(p), extra[0], extra[1], extra[2], extra[3], C.c_void_p(V.data_ptr()), C.c_void_p(Mw.data_ptr()), _stream()),

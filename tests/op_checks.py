@@ -113,8 +113,8 @@ def conv_winograd(dt):
 
 
 def conv_winograd_subbatch(dt):
-    """three-step split-precision Winograd layers under the workspace cap (hip_ops `wino3s`: PF_WS_CAP_GB makes a layer run as sub-batches of its
-    images through one smaller arena pair) and under the measured scheduling switches of csrc/winograd.hip run_split3 (resident transforms
+    """three-step split-precision Winograd layers under the workspace cap (hip_ops.wino3_window: PF_WS_CAP_GB makes a layer run in windows of its
+    Winograd tiles through one smaller arena pair, csrc/winograd.hip run_split3; windows that cut through images and rows, a ragged last window) and under the measured scheduling switches of csrc/winograd.hip run_split3 (resident transforms
     PF_W3_TGRID, capped GEMM grid PF_W3_GRID, GEMM token PF_W3_TOKEN): every variant BIT-IDENTICAL to the plain launch (no op mixes images, the
     switches move work between CUs only), incl. channel-slice views and both residuals."""
     import os
@@ -124,7 +124,7 @@ def conv_winograd_subbatch(dt):
     try:
         os.environ.update(PF_WINOGRAD="4", PF_WINOGRAD_MIN_PIXELS="0", PF_WINO_FUSED="0")
         for i, (B, H, W, cin, cout, kw) in enumerate(((4, 37, 41, 256, 256, dict(act="relu", res=True, res2=True)),
-                                                      (6, 18, 23, 544, 320, dict(relu_in=True)),
+                                                      (6, 30, 43, 544, 320, dict(relu_in=True)),
                                                       (8, 56, 74, 256, 256, dict(act="relu")))):
             g = torch.Generator().manual_seed(700 + i)
             w = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
@@ -134,11 +134,15 @@ def conv_winograd_subbatch(dt):
             r1 = _rand((B, H, W, cout), torch.float32, 720 + i) if kw.get("res") else None
             r2 = _rand((B, H, W, cout + 8), torch.float32, 730 + i)[..., :cout] if kw.get("res2") else None
             outs = []
-            for env in (dict(), dict(PF_WS_CAP_GB="0.004"), dict(PF_WS_CAP_GB="0.0005"), dict(PF_W3_TGRID="8", PF_W3_GRID="64", PF_W3_TOKEN="1")):
+            for env in (dict(PF_WS_CAP_GB="100"), dict(PF_WS_CAP_GB="0.02"), dict(PF_WS_CAP_GB="0.0001"), dict(PF_W3_TGRID="8", PF_W3_GRID="64", PF_W3_TOKEN="1")):
                 for k in keys[3:]:
                     os.environ.pop(k, None)
                 os.environ.update(env)
                 _switches_changed()
+                if "PF_WS_CAP_GB" in env:
+                    from patchfusion_amd import hip_ops
+                    nwin = hip_ops.wino3_window(B, H, W, pw)[1]
+                    assert (nwin == 1) == (env["PF_WS_CAP_GB"] == "100") and (env["PF_WS_CAP_GB"] != "0.0001" or nwin >= 2), (env, nwin)
                 yb = torch.zeros((B, H, W, cout + 16), dtype=torch.float32, device=DEV)
                 hip().conv(x, pw, yb[..., 8:8 + cout], pad=1, act=kw.get("act"), relu_in=kw.get("relu_in", False), res=r1, res2=r2)
                 outs.append(yb)

@@ -19,7 +19,7 @@ x = torch.randn(8, 392, 518, C, device=DEV)
 y = torch.empty(8, 392, 518, C, device=DEV)
 print("| tiles per launch | T | GEMM ms / launch | useful TF/s | of 2500/6 | x launches for 8 tiles = ms | whole layer over 8 tiles at that sub-batch ms | transforms ms |")
 print("|---|---|---|---|---|---|---|---|")
-for b, cap in ((8, "100"), (4, "10"), (2, "5"), (1, "2.5")):
+for b, cap in ((8, "100"), (4, "9.4"), (2, "4.7"), (1, "2.4")):
     T = b * 98 * 130
     V3 = torch.randn(3, 36, C // 32, T, 32, device=DEV).to(torch.bfloat16)
     Mw = torch.empty(36, T, C, device=DEV)
@@ -30,7 +30,7 @@ for b, cap in ((8, "100"), (4, "10"), (2, "5"), (1, "2.5")):
     hip_ops.refresh_env()
     hip_ops.release_workspaces()
     torch.cuda.empty_cache()
-    assert hip_ops.wino3_subbatches(8, 392, 518, pw)[0] == 8 // b
+    assert hip_ops.wino3_window(8, 392, 518, pw)[1] == 8 // b, hip_ops.wino3_window(8, 392, 518, pw)
     ops.conv(x, pw, y, pad=1, act="relu", _timed=2)
     layer = ops.conv(x, pw, y, pad=1, act="relu", _timed=5)
     fl = 36 * 2.0 * T * C * C

@@ -64,9 +64,8 @@ __device__ __forceinline__ void mma_half_f32(const uint4 (&wf)[FN], const uint4 
       }
 }
 
-// Compile-time measurement variants (`make ablate`, never part of libpf_hip.so): PF_ABL_NODMA skips the DMA after
-// the prologue, PF_ABL_NOLDS the fragment ds_reads, PF_ABL_NOBAR the per-step barrier.  Results are wrong by
-// construction; they are only used with pf_conv_timed to locate the bottleneck of a kernel.
+// (The compile-time measurement variants of rounds 1-2 -- no DMA / no LDS reads / no barrier builds, `make ablate` -- were retired in round 5 together
+// with the bf16 tuning they served; their numbers are in profiles/r2_abl_f32.log.)
 
 // 256 bytes of zeros: source of every out-of-image / out-of-range 16-byte vector (conv padding, M/N tails)
 __device__ __attribute__((aligned(256))) unsigned int pf_zero_page[64];
@@ -185,11 +184,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const pf_conv_
     b_ptr[i] = (row < p.w_rows) ? reinterpret_cast<const char*>(wg + (long)row * p.Kpad + j * VEC) : nullptr;
   }
   const int cin_v = p.Cin / VEC;
-#ifdef PF_ABL_ONECHUNK     // measurement build: one K chunk only = launch + prologue + epilogue cost of the kernel
-  const int nk = 1;
-#else
   const int nk = (ntaps * cin_v + 7) / 8;
-#endif
   // this thread's K position: vector index kv = kc*8 + j  ->  (tap = (ky,kx), cv)
   // korder 1 (chunk-major weights): chunk kc is tap kc % ntaps of channel chunk kc / ntaps -> cv = 8 (kc / ntaps) + j
   int tap = p.korder ? 0 : j / cin_v, cv = j - tap * cin_v;
@@ -282,28 +277,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const pf_conv_
   const int a_row_off = (wm * WTM + fr) * 128;  // activations (pixels)
   const int b_row_off = (wn * WTN + fr) * 128;  // weights (channels)
 
-#ifndef PF_ABL_NOPRO
   issue(0, 0);
-#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int kc = 0; kc < nk; ++kc) {
-#ifndef PF_ABL_NODMA
     if (kc + 1 < nk) issue((kc + 1) & 1, kc + 1);   // next chunk lands while this one is multiplied
-#endif
     const char* As = smem + (kc & 1) * STAGE;
     const char* Bs = As + A_BYTES;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int slot = (((s << 2) | fg) ^ swz) << 4;
       uint4 wf[FN], xf[FM];
-#ifdef PF_ABL_NOLDS   // measurement build: operands from registers instead of LDS
-#pragma unroll
-      for (int fn = 0; fn < FN; ++fn) { wf[fn] = make_uint4(slot, kc, lane, fn); asm volatile("" : "+v"(wf[fn].x), "+v"(wf[fn].y), "+v"(wf[fn].z), "+v"(wf[fn].w)); }
-#pragma unroll
-      for (int fm = 0; fm < FM; ++fm) { xf[fm] = make_uint4(slot, kc, lane, fm); asm volatile("" : "+v"(xf[fm].x), "+v"(xf[fm].y), "+v"(xf[fm].z), "+v"(xf[fm].w)); }
-      (void)As; (void)Bs;
-#else
 #pragma unroll
       for (int fn = 0; fn < FN; ++fn) wf[fn] = *reinterpret_cast<const uint4*>(Bs + b_row_off + fn * 16 * 128 + slot);
 #pragma unroll
@@ -311,14 +295,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const pf_conv_
         xf[fm] = *reinterpret_cast<const uint4*>(As + a_row_off + fm * 16 * 128 + slot);
         if constexpr (RELU_IN) xf[fm] = relu_vec<T>(xf[fm]);
       }
-#endif
       if constexpr (sizeof(T) == 2) mma_half_bf16<FM, FN>(wf, xf, acc);
       else mma_half_f32<FM, FN>(wf, xf, acc);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk kc+1 has landed (this wave's pieces) ...
-#ifndef PF_ABL_NOBAR
     __syncthreads();                                    // ... for every wave; and stage kc&1 is free again
-#endif
   }
 
   // ---- epilogue: bias -> act -> scale -> residual(s) -> store 4 consecutive channels ----
@@ -396,12 +377,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const pf_conv_
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += t[r];
       }
-#ifdef PF_ABL_NOSTORE
-      if (v[0] == 12345.678f) store4(reinterpret_cast<T*>(p.y) + opix * p.y_ld + co, v[0], v[1], v[2], v[3]);
-#else
       if (p.out_f32) store4(reinterpret_cast<float*>(p.y) + plane * (size_t)p.y_bstride + opix * p.y_ld + co, v[0], v[1], v[2], v[3]);
       else store4(reinterpret_cast<T*>(p.y) + plane * (size_t)p.y_bstride + opix * p.y_ld + co, v[0], v[1], v[2], v[3]);
-#endif
     }
   }
 }
@@ -908,11 +885,7 @@ __device__ __forceinline__ void lds_wait(u32x4& a, u32x4& b, u32x4& c, u32x4& d,
   a = ta; b = tb; c = tc; d = td; e = te; f = tf;
 }
 
-#ifdef PF_HALO_NOROLL     // A/B builds only: leave the fragment reads of the halo kernels to hipcc's scheduler
-constexpr bool kHaloRoll = false;
-#else
 constexpr bool kHaloRoll = true;
-#endif
 
 template <int WN, int FM, int FN, bool RELU_IN>
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params p) {
@@ -1035,12 +1008,10 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params 
   int chunk = 0, ky = 0;
   for (int g = 0; g < G; ++g) {
     // ---- loader waves: a third of the next chunk's halo, then the weight rows of step g+1 (other ring slot) ----
-#ifndef PF_ABL_NODMA   // (compile-time measurement variants: make ablate; never part of libpf_hip.so)
     if (loader) {
       if (chunk + 1 < nchunks) issue_a(ky, chunk + 1);
       if (g + 1 < G) issue_w(g + 1);
     }
-#endif
     // ---- multiply filter row ky (three taps) of this chunk ----
     const char* Ab = smem + (chunk & 1) * A_BUF;
     const char* Wb = smem + LDS_W0 + (g & 1) * W_STAGE;
@@ -1193,13 +1164,6 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params 
       for (int t = 0; t < 2; ++t) {
         const int slot = (t << 1) | fh;
         uint4 wf[FN], xf[FM];
-#ifdef PF_ABL_NOLDS
-#pragma unroll
-        for (int fn = 0; fn < FN; ++fn) { wf[fn] = make_uint4(slot, tap_off, lane, fn); asm volatile("" : "+v"(wf[fn].x)); }
-#pragma unroll
-        for (int fm = 0; fm < FM; ++fm) { xf[fm] = make_uint4(slot, tap_off, lane, fm); asm volatile("" : "+v"(xf[fm].x)); }
-        (void)Ab; (void)Wb;
-#else
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn)
           wf[fn] = *reinterpret_cast<const uint4*>(Wb + kx * W_TILE + w_off[fn] + ((slot ^ w_swz[fn]) << 4));
@@ -1209,27 +1173,18 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const pf_conv_params 
           xf[fm] = *reinterpret_cast<const uint4*>(Ab + row * 64 + ((slot ^ ((row >> 2) & 3)) << 4));
           if constexpr (RELU_IN) xf[fm] = relu_vec<T>(xf[fm]);
         }
-#endif
-#ifdef PF_HALO_SETPRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn)
 #pragma unroll
           for (int fm = 0; fm < FM; ++fm)
             acc[fn][fm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[fn]),
                                                                   __builtin_bit_cast(bf16x8, xf[fm]), acc[fn][fm], 0, 0, 0);
-#ifdef PF_HALO_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
       }
     }
     }
     // ---- everything issued this step (weights of g+1, halo pieces) has a whole step of MFMA to land ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifndef PF_ABL_NOBAR
     __syncthreads();
-#endif
     if (++ky == 3) { ky = 0; ++chunk; }
   }
 

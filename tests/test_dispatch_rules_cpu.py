@@ -61,6 +61,33 @@ def test_fused_versus_three_step_rule(monkeypatch):
     assert fw(1, 28, 37, p768)
 
 
+def test_three_step_layers_walk_their_tiles_in_capped_windows(monkeypatch):
+    """hip_ops.wino3_window (round 5): the V + M arena pair of a three-step layer is capped (PF_WS_CAP_GB, default 2.5); larger layers run in windows of
+    their Winograd tiles -- multiples of the GEMM's 192-token tile, the last one ragged -- through that one pair."""
+    try:
+        hip_ops = importlib.import_module("patchfusion_amd.hip_ops")
+    except Exception as e:
+        pytest.skip(f"libpf_hip.so not built: {e}")
+    from types import SimpleNamespace as NS
+    monkeypatch.delenv("PF_WS_CAP_GB", raising=False)
+    hip_ops.refresh_env()
+    pw = NS(cin=544, cout=544)
+    T = 8 * 98 * 130
+    win, nwin, nV, nM = hip_ops.wino3_window(8, 392, 518, pw)
+    assert win % 192 == 0 and nwin == -(-T // win) and (nV + nM) * 4 <= 2.5 * 2 ** 30 < (36 * (win + 192) * 544 * 10)
+    assert nV * 4 >= 36 * win * 544 * 6 and nM == 36 * win * 544 and nwin == 8                      # the headline layer: eight windows of 2.3 GB
+    small = hip_ops.wino3_window(8, 56, 74, NS(cin=256, cout=256))
+    assert small[1] == 1 and small[0] == -(-(8 * 14 * 19) // 8) * 8                                 # fits: one window = all tiles (whole octets)
+    monkeypatch.setenv("PF_WS_CAP_GB", "0.000001")                                                  # never below one GEMM tile of tokens
+    hip_ops.refresh_env()
+    assert hip_ops.wino3_window(8, 392, 518, pw)[:2] == (192, -(-T // 192))
+    monkeypatch.setenv("PF_WS_CAP_GB", "100")
+    hip_ops.refresh_env()
+    assert hip_ops.wino3_window(8, 392, 518, pw)[:2] == (T, 1)
+    monkeypatch.delenv("PF_WS_CAP_GB")
+    hip_ops.refresh_env()
+
+
 def test_split_gemm_kernel_choice_by_shape(monkeypatch):
     """pf_gemm_split3_route (csrc/gemm_split3.hip split3_route, no launch, no GPU): which of the four split-GEMM kernels a call runs on a 256-CU chip --
     the launches of the 4K ViT-L pass named in DESIGN.md 4g.  Round 4's rule: persistent from two rounds of 128 x 128 tiles on, 192 x 192 tiles when

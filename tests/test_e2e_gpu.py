@@ -361,3 +361,27 @@ print('rccl-ok')
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "rccl-ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_free_parameters_keeps_the_numbers_and_refuses_what_it_cannot_do():
+    """PatchFusion.free_parameters() (opt-in, round 5): once the engine holds every layer in packed form the unpacked checkpoint tensors are released;
+    forward results stay BIT-identical, state_dict() / .to() refuse with a clear message, load_state_dict() restores the normal state."""
+    cfg, sd, m, img = build(*TINY, "fp32")
+    lr = m.resizer(img).cuda()
+    with torch.no_grad():
+        d0, _ = m(mode="infer", image_lr=lr, image_hr=img.cuda(), cai_mode="m1", process_num=2)
+    before = sum(p.numel() for p in m.parameters())
+    m.free_parameters()
+    assert sum(p.numel() for p in m.parameters()) == 0 and before > 0
+    with torch.no_grad():
+        d1, _ = m(mode="infer", image_lr=lr, image_hr=img.cuda(), cai_mode="m1", process_num=2)
+    assert torch.equal(d0, d1)
+    with pytest.raises(RuntimeError, match="free_parameters"):
+        m.state_dict()
+    with pytest.raises(RuntimeError, match="free_parameters"):
+        m.cpu()
+    m.load_state_dict(sd, strict=True)                          # back to the normal state: parameters on the device again, engine rebuilt on demand
+    assert sum(p.numel() for p in m.parameters()) == before and next(m.parameters()).is_cuda
+    with torch.no_grad():
+        d2, _ = m(mode="infer", image_lr=lr, image_hr=img.cuda(), cai_mode="m1", process_num=2)
+    assert torch.equal(d0, d2) and len(m.state_dict()) == len(sd)

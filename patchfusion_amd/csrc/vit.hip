@@ -743,6 +743,9 @@ __global__ __launch_bounds__(256, QG == 1 ? 3 : 2) void vit_attention_qkv_f32_ke
 // S^T fragment kf (16 keys): A = K rows (lane (r = key, g): d = 32 kh + 8 g ..), B = Q (lane (r = query, g): same d) -> lane (query r, g)
 // holds keys 16 kf + 4 g + e.  O^T fragment df (16 d): A = V^T rows (lane (r = d, g): the eight permuted keys of block kk), B = P.
 // ---------------------------------------------------------------------------------------------------------------------------------------
+// (Measured and NOT kept, round 5: loading the K / V rows of key tile kt+1 into the 48 staging registers BEFORE the MFMA / softmax work of tile kt --
+// 217 registers, two blocks per CU instead of three: 310 vs 285 us at B = 8, the image pass +1.2 ms, profiles/r5_attention_prefetch.md.  Three
+// resident blocks cover the load latency better than a prefetch in two.)
 __global__ __launch_bounds__(256, 3) void vit_attention_split3_kernel(const bf16_t* __restrict__ qkv3, long plane_in, bf16_t* __restrict__ out3,
                                                                       long plane_out, int B, int S, int Hh, float qscale, long kmaj_rows) {
   __shared__ __attribute__((aligned(16))) char lds[2 * 3 * 64 * 128];

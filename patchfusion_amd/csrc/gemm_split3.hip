@@ -732,7 +732,21 @@ __global__ __launch_bounds__(512) void gemm_split3_persist192_kernel(const pf_co
   const int fr = lane & 15, fg = lane >> 4;
   const int slot = (fg ^ ((fr >> 1) & 3)) << 4;
   const int x_off = (wm * WTM + fr) * 64 + slot;
-  const int w_off = NP * BM * 64 + (wn * WTN + fr) * 64 + slot;
+  // NARROW LAST COLUMN TILE (round 5): when the tile has nv < BN valid columns (N = 544: 160 of 192) the two wave columns share them evenly --
+  // cur_nfn = ceil(ceil(nv / 16) / WN) fragments of 16 columns per wave (5 instead of 6: 90 MFMAs per chunk and wave instead of 108, on BOTH wave columns,
+  // where a fixed 96 + 96 split leaves wave column 0 at 108 and wave column 1 multiplying 32 dead columns) -- the fragments above cur_nfn are neither read
+  // nor multiplied nor stored.  Same products in the same order for every output element (bit-identical).  Never fewer than NFN_MIN = 3 (the guard is a
+  // wave-uniform branch only on the fragments above it).
+  constexpr int NFN_MIN = 3;
+  int cur_nfn = FN, cur_wtn = WTN, e_nfn = FN, e_wtn = WTN;
+  int w_off = NP * BM * 64 + (wn * WTN + fr) * 64 + slot;
+  auto tile_shape = [&](int n0) __attribute__((always_inline)) {
+    if (!(flags & 8)) return;                            // (A/B: PF_S3_FLAGS without bit 3 keeps the fixed 96 + 96 split)
+    const int nv = min(BN, p.Cout - n0);
+    cur_nfn = min(FN, max(NFN_MIN, ((nv + 15) / 16 + WN - 1) / WN));
+    cur_wtn = cur_nfn * 16;
+    w_off = NP * BM * 64 + (wn * cur_wtn + fr) * 64 + slot;
+  };
   struct Frags { uint4 w[NP][FN], x[NP][FM]; };
   Frags f;
   int s_read = 0;
@@ -742,7 +756,8 @@ __global__ __launch_bounds__(512) void gemm_split3_persist192_kernel(const pf_co
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
-      for (int fn = 0; fn < FN; ++fn) f.w[pl][fn] = *reinterpret_cast<const uint4*>(S + w_off + pl * (BN * 64) + fn * 1024);
+      for (int fn = 0; fn < FN; ++fn)
+        if (fn < NFN_MIN || fn < cur_nfn) f.w[pl][fn] = *reinterpret_cast<const uint4*>(S + w_off + pl * (BN * 64) + fn * 1024);
 #pragma unroll
       for (int fm = 0; fm < FM; ++fm) f.x[pl][fm] = *reinterpret_cast<const uint4*>(S + x_off + pl * (BM * 64) + fm * 1024);
     }
@@ -755,8 +770,9 @@ __global__ __launch_bounds__(512) void gemm_split3_persist192_kernel(const pf_co
       piece(((TI) * FN * FM + fn * FM + fm) / MPP);                                                                            \
       __builtin_amdgcn_sched_barrier(0);                                                                                       \
     }                                                                                                                          \
-    acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.w[PW][fn]), __builtin_bit_cast(bf16x8, f.x[PX][fm]), \
-                                                          acc[fn][fm], 0, 0, 0);                                               \
+    if (fn < NFN_MIN || fn < cur_nfn)                                                                                          \
+      acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.w[PW][fn]), __builtin_bit_cast(bf16x8, f.x[PX][fm]), \
+                                                            acc[fn][fm], 0, 0, 0);                                             \
   }
   auto multiply = [&](auto with_issue) __attribute__((always_inline)) {
     constexpr bool ISS = decltype(with_issue)::value;
@@ -785,8 +801,9 @@ __global__ __launch_bounds__(512) void gemm_split3_persist192_kernel(const pf_co
 #pragma unroll
     for (int fn = 0; fn < FN; fn += 2) {
       __builtin_amdgcn_sched_barrier(0);                 // one fragment pair at a time (register pressure)
-      const int n = e_n0 + wn * WTN + (fn + (lo ? 0 : 1)) * 16 + fg * 4;
-      const bool nok = n < p.Cout;
+      const int fsel = fn + (lo ? 0 : 1);                // the fragment whose values this lane stores
+      const int n = e_n0 + wn * e_wtn + fsel * 16 + fg * 4;
+      const bool nok = n < p.Cout && fsel < e_nfn;
       float4 bias_r = make_float4(0.f, 0.f, 0.f, 0.f), scale_r = make_float4(1.f, 1.f, 1.f, 1.f);
       if constexpr (!BARE) {
         if (nok) {
@@ -870,8 +887,15 @@ __global__ __launch_bounds__(512) void gemm_split3_persist192_kernel(const pf_co
   };
   auto tile_cursor = [&]() __attribute__((always_inline)) {     // head of a load phase: stores of the finished tile, coordinates of the ending one
     if (epi_pending) epilogue();                        // beside the partner group's MFMAs
+    if (c_kc == 0) {                                    // a tile begins: its column shape (narrow last column tile)
+      int z, m0, n0;
+      decode(l_comp, z, m0, n0);
+      tile_shape(n0);
+    }
     if (c_kc == nk - 1) {
       decode(l_comp, e_z, e_m0, e_n0);
+      e_nfn = cur_nfn;
+      e_wtn = cur_wtn;
       l_comp += nb;
     }
   };
@@ -1009,9 +1033,9 @@ int cu_count() {
 // would fall into DIFFERENT iterations of the 32-block XCD (46 us apart: an L2 miss each) -- those run channel-tile-fastest instead (returned as
 // gm = 0): the nt sharers of a token tile are adjacent in the order, all W panels (nt x 209 KB at K = 544) stay hot.  PF_S3_ORDER=0: the patches.
 // Round 5: the same holds for the "aligned" nt (2, 4, 8, 16, 22 ...) -- the XCD ranges and per-plane tile counts are not multiples of 32, so the
-// patches split 70 % of their panels too (host replay, tests/test_split3_schedule_model_cpu.py) -- measured per launch (profiles/r5_order_sweep.md):
-// 768->768 (nt = 4) 1.07-1.18x, 768->256 / 256->256 (nt = 2) 1.03-1.06x, ViT qkv / fc1 / fc2 1.07-1.13x, the 8296 x 1024 projection 0.96x; the image
-// pass -1.0 / -3.0 ms in two interleaved A/Bs.  Channel tile fastest is therefore the default for every nt >= 2 (PF_S3_ORDER=1: the round-4 rule).
+// patches split 70 % of their panels too (host replay, tests/test_split3_schedule_model_cpu.py) -- measured per launch (profiles/r5_order_sweep_unbiased.md):
+// fc1 1.07x, the 8296 x 1024 projection 1.04x, the N = 256 layers 1.03x, 768->768 (nt = 4) 1.01-1.02x; the image pass -1.0 / -3.0 / -2.2 ms in three
+// interleaved A/Bs.  Channel tile fastest is therefore the default for every nt >= 2 (PF_S3_ORDER=1: the round-4 rule).
 int tile_group(int nt) {
   const char* s = getenv("PF_S3_ORDER");
   const char o = s ? s[0] : '2';
@@ -1085,7 +1109,7 @@ int launch_persist192(const pf_conv_params& p, hipStream_t st, int grid_cap) {
 #endif
   const char* bls = getenv("PF_S3_BLOAD");                               // (A/B: 0 = group B issues between its MFMAs, the round-4 schedule)
   const bool bl = !(bls && bls[0] == '0');
-  int flags = 2;                                                         // bit 1: whole-line stores of the float32 tile (A/B: PF_S3_FLAGS=0)
+  int flags = 8;                                                         // bit 3: narrow last column tile shared evenly by the wave columns (A/B: PF_S3_FLAGS=0)
   if (const char* s = getenv("PF_S3_FLAGS")) flags = atoi(s);
   if (bare && bl) hipLaunchKernelGGL((gemm_split3_persist192_kernel<true, true>), dim3((unsigned)grid), dim3(512), smem, st, p, mt, nt, gm, (int)total, flags);
   else if (bare) hipLaunchKernelGGL((gemm_split3_persist192_kernel<true, false>), dim3((unsigned)grid), dim3(512), smem, st, p, mt, nt, gm, (int)total, flags);

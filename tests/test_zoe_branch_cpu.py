@@ -122,7 +122,7 @@ def test_zoe_branch_checkpoint_with_core_weights_loads_through_the_configdict_ro
 
     c = ConfigDict(cfg)
     c["pretrain_model"] = paths
-    with pytest.warns(UserWarning, match="NOT loaded"):       # the stand-in cores cannot take weights: said aloud, not dropped silently
+    with pytest.warns(UserWarning, match="kept and handed to the provider"):   # the stand-in cores cannot take weights: said aloud, not dropped silently
         m = PatchFusion(c, ops=fake_ops, core_providers=(StandInCore(11), StandInCore(12)))
     assert m.config.load_branch is True
 
@@ -137,6 +137,21 @@ def test_zoe_branch_checkpoint_with_core_weights_loads_through_the_configdict_ro
         warnings.simplefilter("error")
         PatchFusion(c, ops=fake_ops, core_providers=taking)
     assert all(len(t.loaded) == 2 for t in taking)
+    # round-4 advisor finding: providers injected AFTER construction still receive the checkpoint's `core.` weights (they were kept, not dropped)
+    late = (TakingCore(11), TakingCore(12))
+    m.set_core_providers(*late)
+    assert all(len(t.loaded) == 2 for t in late) and m._pending_core_sd == [None, None]
+    # ... and a branch checkpoint that fails its own strict check must not have touched the injected core
+    untouched = (TakingCore(11), TakingCore(12))
+    broken = torch.load(paths[1])
+    broken["model_state_dict"].pop("conv2.weight")
+    bp = str(tmp_path / "fine_missing.pth")
+    torch.save(broken, bp)
+    c2 = ConfigDict(cfg)
+    c2["pretrain_model"] = [paths[0], bp]
+    with pytest.raises(RuntimeError, match="Missing"):
+        PatchFusion(c2, ops=fake_ops, core_providers=untouched)
+    assert not hasattr(untouched[1], "loaded")
     got = m.state_dict()
     assert all(torch.equal(got[k], v) for k, v in sd.items() if k.startswith(("coarse_branch.", "fine_branch.")))
     # an unknown non-core key is still an error, like load_state_dict(strict=True)

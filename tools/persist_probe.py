@@ -215,11 +215,18 @@ def _sweep(knob, only_wino=False):
     g = torch.Generator(device=DEV).manual_seed(0)
 
     def row(name, fl, fn):
-        ts = []
-        for v in p2s:
-            for nm in names:
-                os.environ[nm] = v
-            ts.append(fn())
+        # (round 5: an untimed pass first, then THREE interleaved rounds over the variants, mean per variant -- the first timing after the tensors are made runs on
+        #  a cold clock: a single A, B pass credited the second arm with up to 14 % it had not earned, profiles/r5_sweep_order_bias.md)
+        for nm in names:
+            os.environ[nm] = p2s[0]
+        fn()
+        acc = [0.0] * len(p2s)
+        for _ in range(3):
+            for i, v in enumerate(p2s):
+                for nm in names:
+                    os.environ[nm] = v
+                acc[i] += fn()
+        ts = [a / 3 for a in acc]
         for nm in names:
             os.environ.pop(nm, None)
         b = min(range(len(ts)), key=lambda i: ts[i])

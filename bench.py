@@ -348,7 +348,7 @@ def roofline(dtype, dev, gemm_only=False):
     direct-convolution FLOPs it replaces per second (which may exceed the MFMA peak: Winograd multiplies 36 / 144 as often).
     PF_WINOGRAD=0: the direct f32 kernel on the 3x3 layer, as in bf16.
     `traffic` (HBM bytes per launch from the rocprofv3 PMC passes, which cannot run inside bench.py) is reported only when
-    profiles/r4_pmc_dominant_<dtype>.json was measured on EXACTLY this kernel source (sha of igemm.hip + wino_fused.hip + gemm_split3.hip + winograd.hip + pf_common.h); otherwise null.
+    profiles/r5_pmc_dominant_<dtype>.json was measured on EXACTLY this kernel source (sha of igemm.hip + wino_fused.hip + gemm_split3.hip + winograd.hip + pf_common.h); otherwise null.
     NOTE on its meaning: FETCH_SIZE / WRITE_SIZE count the L2's fabric-side requests; reads served by the 256 MiB Infinity Cache are included, so
     for the fused Winograd kernel (whose 43 MB filter set and 10 MB halo groups are re-streamed through L2 by design) it is an UPPER bound on HBM bytes."""
     from patchfusion_amd import hip_ops
@@ -361,7 +361,7 @@ def roofline(dtype, dev, gemm_only=False):
     pw = pk.pack_conv(w, torch.zeros(C), dtype=tdt).to(dev)
     peak = PEAK_TFLOPS[dtype]
     traffic = None
-    for rnd in ("r4", "r3"):              # the newest PMC summary measured on EXACTLY this kernel source
+    for rnd in ("r5", "r4", "r3"):        # the newest PMC summary measured on EXACTLY this kernel source
         try:
             with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_dominant_{dtype}.json")) as f:
                 j = json.load(f)

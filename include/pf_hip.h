@@ -133,6 +133,13 @@ int pf_vit_attention_qkv_split3(const void* qkv, void* out3, long plane, int kma
  * elements), out3 = three bf16 planes [3][B*S][Hh*64] (plane_out); S^T = K.Q^T and O^T = V^T.P^T as six bf16 partial products each with float32
  * accumulation, float32 softmax with the probabilities split in registers (csrc/vit.hip vit_attention_split3_kernel; attention.py:53-60). */
 int pf_vit_attention_split3(const void* qkv3, long plane_in, void* out3, long plane_out, int kmajor, int B, int S, int Hh, void* stream);
+/* Version 2 of the same operator (csrc/attn_split3.hip; same operands): K / V tiles by LDS-DMA, V^T fragments by the transposing LDS read, 32 (or
+ * 16) queries per wave.  queries_per_wave: 16, 32, or 0 = 32 when the launch fills the chip with 128-query blocks, else 16.  schedule: 1 = the
+ * two-phase kernel (64-key tiles; bit-identical to pf_vit_attention_split3), 2 = the software-pipelined kernel (32-key blocks, QK / softmax / PV of
+ * three consecutive blocks overlapped inside every wave; float32-rounding-identical), 0 = default (2).  Requires S * Hh * 384 bytes < 2^31 (32-bit
+ * row offsets inside one image).  Replaces dinov2/layers/attention.py:53-60. */
+int pf_vit_attention_split3_v2(const void* qkv3, long plane_in, void* out3, long plane_out, int kmajor, int B, int S, int Hh, int queries_per_wave,
+                               int schedule, void* stream);
 /* float32 [rows][x_ld] -> three bf16 planes [3][rows][y_ld], plane stride `plane` elements (the split producers fuse into their stores) */
 int pf_split3(const float* x, int x_ld, void* y, int y_ld, long plane, long rows, int cols, void* stream);
 

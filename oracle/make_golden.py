@@ -20,6 +20,9 @@ tools/test.py:122-123 fix_random_seed):
               (`python -m oracle.make_golden variants` regenerates only this file)
   headline_vitl_ref: the HEADLINE architecture (DA-vitl, process 392x518) from the reference itself: one 2160x3840 image, 2x2 tiles, m1,
               process_num=4; sampled final map + coarse depth + two coarse feature levels (`python -m oracle.make_golden vitl`; ~1-2 CPU-minutes)
+  cfg2_vitl_ref / cfg3_vitl_ref: the BENCHED configurations themselves from the reference itself - BASELINE.json configs[2] (DA-vitl, 2160x3840,
+              4x4 tiles, m1, process_num=8; 16 patches) and the configs[3] geometry (8x8 tiles, m1, process_num=8; 64 patches): the same four
+              sampled tensors as headline_vitl_ref (`python -m oracle.make_golden cfg2` ~5 CPU-minutes, `... cfg3` ~20 CPU-minutes on 8 threads)
 """
 import os
 import random
@@ -74,18 +77,19 @@ def cfg4k():
     np.savez_compressed(os.path.join(OUT, "cfg4k_vits.npz"), **out)
 
 
-def vitl():
-    """The HEADLINE architecture from the reference itself (round-4 review, missing #5): DA-vitl, process 392x518, one 2160x3840 image cut in
+def vitl(split=(2, 2), process_num=4, fname="headline_vitl_ref.npz"):
+    """(split, process_num, file) = ((2, 2), 4, headline_vitl_ref) | ((4, 4), 8, cfg2_vitl_ref) | ((8, 8), 8, cfg3_vitl_ref).
+    The HEADLINE architecture from the reference itself (round-4 review, missing #5): DA-vitl, process 392x518, one 2160x3840 image cut in
     2x2 tiles, cai_mode m1, process_num 4 -- the reference's own PatchFusion.forward(mode='infer') (patchfusion.py:401-453; ViT-L widths
     depth_anything.py:346-352) on the seeded weights / image every headline test uses.  Stored: 8192 sampled values of the final map, 4096 of the
     coarse depth, 2048 of coarse feature level 3 (r2, 256 @ 112x148) and level 5 (out_conv, 32 @ 392x518), + stats.  ~1 CPU-minute on 8 threads."""
-    m, cfg, img = build("vitl", (392, 518), (2160, 3840), (2, 2))
+    m, cfg, img = build("vitl", (392, 518), (2160, 3840), split)
     lr = m.resizer(img)
     out = {}
     with torch.no_grad():
         random.seed(5621)
         cd, cf = m.coarse_forward(lr)
-        d, _ = m(mode="infer", image_lr=lr, image_hr=img, cai_mode="m1", process_num=4)
+        d, _ = m(mode="infer", image_lr=lr, image_hr=img, cai_mode="m1", process_num=process_num)
     for name, t, k, seed in (("depth_m1", d, 8192, 21), ("coarse_depth", cd, 4096, 22), ("coarse_feat3", cf[3], 2048, 23), ("coarse_feat5", cf[5], 2048, 24)):
         flat = t.flatten()
         idx = sample_idx(flat.numel(), k, seed)
@@ -94,7 +98,7 @@ def vitl():
         out[name + "_val"] = flat[idx].numpy()
         out[name + "_stats"] = np.array([t.mean().item(), t.std().item(), t.min().item(), t.max().item()], np.float32)
         print(name, tuple(t.shape), out[name + "_stats"], flush=True)
-    np.savez_compressed(os.path.join(OUT, "headline_vitl_ref.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
 
 
 VARIANTS = (("normed", "inv", "mean"), ("hybrid1", "exp", "sum"), ("hybrid2", "inv", "sum"), ("softplus", "exp", "mean"))
@@ -140,6 +144,12 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "vitl":
         vitl()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "cfg2":
+        vitl((4, 4), 8, "cfg2_vitl_ref.npz")
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "cfg3":
+        vitl((8, 8), 8, "cfg3_vitl_ref.npz")
+        return
     # ---------------- tiny ----------------
     m, cfg, img = build("vits", (112, 154), (448, 616), (2, 2))
     lr = m.resizer(img)
@@ -178,6 +188,8 @@ def main():
     cfg4k()
     variants()
     vitl()
+    vitl((4, 4), 8, "cfg2_vitl_ref.npz")
+    vitl((8, 8), 8, "cfg3_vitl_ref.npz")
 
 
 if __name__ == "__main__":

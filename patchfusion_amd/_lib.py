@@ -65,6 +65,7 @@ SIGNATURES = {
     "pf_layernorm_split3": [vp, ci, vp, ci, cl, ci, vp, vp, cf, cl, ci, vp],
     "pf_vit_attention_qkv_split3": [vp, vp, cl, ci, ci, ci, ci, vp],
     "pf_vit_attention_split3": [vp, cl, vp, cl, ci, ci, ci, ci, vp],
+    "pf_vit_attention_split3_v2": [vp, cl, vp, cl, ci, ci, ci, ci, ci, ci, vp],
     "pf_conv_winograd_fused": [C.POINTER(ConvParams), vp, ci, ci, vp],
     "pf_conv_winograd_fused_timed": [C.POINTER(ConvParams), vp, ci, ci, ci, C.POINTER(cf), vp],
     "pf_attractor": [vp, ci, ci, ci, cf, ci, ci, vp, ci, ci, vp, ci, ci, ci, ci, vp],

@@ -503,6 +503,12 @@ class HipOps:
             assert qkv.dtype == out.dtype == torch.bfloat16 and tuple(qkv.shape) == (3, B * S, 3 * D)
             assert tuple(out.shape) == ((3, D // 32, B * S, 32) if kmaj else (3, B * S, D))
             assert D == heads * 64 and qkv.is_contiguous() and out.is_contiguous()
+            # PF_ATTN_V2 (default 1): csrc/attn_split3.hip (LDS-DMA tiles, transposing V reads); PF_ATTN_QW = 16 / 32 forces the queries per wave
+            # (0: by launch size), PF_ATTN_SCHED = 1 the two-phase kernel (bit-identical to version 1) / 2 the software-pipelined kernel (0: default)
+            if _env("PF_ATTN_V2", "1") != "0":
+                check(_L.pf_vit_attention_split3_v2(_p(qkv), qkv.stride(0), _p(out), out.stride(0), kmaj, B, S, heads, int(_env("PF_ATTN_QW", "0")),
+                                                    int(_env("PF_ATTN_SCHED", "0")), _stream()), "pf_vit_attention_split3_v2")
+                return
             check(_L.pf_vit_attention_split3(_p(qkv), qkv.stride(0), _p(out), out.stride(0), kmaj, B, S, heads, _stream()), "pf_vit_attention_split3")
             return
         D = qkv.shape[1] // 3

@@ -83,14 +83,15 @@ def test_fused_winograd_kernel_resources_and_hand_counted_vmem(tmp_path):
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
-@pytest.mark.parametrize("src_name,min_kernels", [("gemm_split3.hip", 8), ("vit.hip", 14)])
+@pytest.mark.parametrize("src_name,min_kernels", [("gemm_split3.hip", 8), ("vit.hip", 14), ("attn_split3.hip", 3)])
 def test_split_precision_and_vit_kernels_have_no_scratch(tmp_path, src_name, min_kernels):
     """csrc/gemm_split3.hip (210 - 251 VGPRs: two 72-register fragment sets + accumulators at two waves per SIMD) and csrc/vit.hip (the split
-    attention kernel runs three blocks per CU = 168 registers and spilled 12 B/lane in round 3): no scratch anywhere, at most 256 registers"""
+    attention kernel runs three blocks per CU = 168 registers and spilled 12 B/lane in round 3): no scratch anywhere, at most 256 registers; csrc/attn_split3.hip (round 6: the pipelined attention holds Q, O, two S and two P
+    register sets and two fragment sets -- 250 registers at two blocks per CU; its softmax slices must stay between its MFMAs)"""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     src = os.path.join(ROOT, "patchfusion_amd", "csrc", src_name)
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result", "-c", src,
-                        "-o", str(tmp_path / "k.o"), "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900)
+                        "-o", str(tmp_path / "k.o"), "-Rpass-analysis=kernel-resource-usage", "-save-temps=obj"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     names = re.findall(r"Function Name: (\S+)", r.stderr)
     scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
@@ -101,3 +102,27 @@ def test_split_precision_and_vit_kernels_have_no_scratch(tmp_path, src_name, min
     if src_name == "vit.hip":
         att = [v for n, v in zip(names, vgprs) if "vit_attention_split3_kernel" in n]
         assert att and att[0] <= 168, att          # three blocks per CU
+    if src_name == "attn_split3.hip":
+        # the steady step of the pipelined kernel must come out INTERLEAVED: between two barriers of the tile loop no run of more than 5 MFMAs without
+        # another instruction between them (an un-fenced build put all 48 MFMAs first and the softmax after them: same results, no overlap)
+        listing = [f for f in os.listdir(tmp_path) if f.endswith("gfx950.s")]
+        assert listing, os.listdir(tmp_path)
+        txt = open(tmp_path / listing[0]).read()
+        body = txt[txt.index("vit_attention_split3_pipe_kernel"):]
+        body = body[:body.index("s_endpgm")]
+        ops = [ln.split()[0] for ln in body.splitlines() if ln.startswith("\t") and ln.strip() and not ln.strip().startswith((";", "."))]
+        regions, cur = [], []
+        for op in ops:
+            if op == "s_barrier":
+                regions.append(cur)
+                cur = []
+            else:
+                cur.append(op)
+        steady = [r for r in regions if sum(o.startswith("v_mfma_f32_32x32x16") for o in r) == 48 and sum(o == "v_exp_f32_e32" for o in r) >= 16]
+        assert len(steady) >= 2, [sum(o.startswith("v_mfma") for o in r) for r in regions]
+        for r in steady:
+            run = worst = 0
+            for o in r:
+                run = run + 1 if o.startswith("v_mfma") else 0
+                worst = max(worst, run)
+            assert worst <= 6, worst

@@ -179,8 +179,14 @@ def main():
                          "PF_WS_CAP_GB = 2.5 GB: larger layers run as sub-batches of their tiles); PatchFusion.free_parameters() (opt-in) returns another ~2.7 GB")
     if world > 1:
         out["rank_seconds"] = rank_s[args.dtype]
+        # self-diagnosis of the first real multi-GPU run (round-5 review item 8): the communicator's own size after an actual collective on the device, and
+        # the tile-depth gather of one image pass on its own -- [P, 392, 518] float32 through patchfusion_amd.dist.all_gather_shards (one
+        # all_gather_into_tensor over RCCL), timed with a barrier on both sides, maximum over ranks, after one untimed call (RCCL sets its rings up lazily)
+        out["rccl"] = gather_diagnosis(P, (392, 518), world, dev, barrier, ms)
     if rank == 0 and not args.no_roofline:
         out["roofline"] = roofline(args.dtype, dev)
+        if args.dtype == "fp32" and split3_on():
+            out["roofline"]["attention"] = roofline_attention(dev)       # the second north-star kernel beside the dominant launch (round-5 review item 7)
         log(f"roofline: {out['roofline']}")
     if N == 1 and args.dtype == "fp32" and not args.no_secondary and split3_on():
         # the same pass with every GEMM on the float32 MFMA (PF_LINEAR_SPLIT3=0 PF_WINO_SPLIT3=0): the number to quote if split-precision linears are not
@@ -217,6 +223,30 @@ def main():
     if world > 1:
         barrier()                      # the other ranks wait for rank 0's roofline launch, then all leave together
         torch.distributed.destroy_process_group()
+
+
+def gather_diagnosis(P, tile_hw, world, dev, barrier, ms_per_step):
+    """The communicator's size after an actual collective and the tile-depth gather of one image pass on its own: [P, h, w] float32 through
+    patchfusion_amd.dist.all_gather_shards (one all_gather_into_tensor), a barrier on both sides, maximum over ranks, after one untimed call."""
+    import torch.distributed as dist
+    from patchfusion_amd.dist import all_gather_shards
+    from patchfusion_amd.tiling import shard_range
+    tiles = torch.zeros(P, *tile_hw, device=dev)
+    lo, hi = shard_range(P, dist.get_rank(), world)
+    tiles[lo:hi] = dist.get_rank() + 1.0
+    g_out = all_gather_shards(tiles, P, world)
+    ok = all(bool((g_out[slice(*shard_range(P, r, world))] == r + 1.0).all()) for r in range(world))      # every rank's rows arrived in tile order
+    barrier()
+    t0 = time.perf_counter()
+    n_g = 10
+    for _ in range(n_g):
+        g_out = all_gather_shards(tiles, P, world)
+    barrier()
+    tg = torch.tensor([(time.perf_counter() - t0) / n_g * 1e3], device=dev, dtype=torch.float64)
+    dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+    return {"ranks": dist.get_world_size(), "backend": dist.get_backend(), "tile_gather_ms": round(float(tg.item()), 4), "rows_in_tile_order": ok,
+            "tile_gather_bytes_per_rank": int(tiles[0].numel() * 4 * (hi - lo)), "gathered_shape": list(g_out.shape),
+            "share_of_ms_per_step": round(float(tg.item()) / ms_per_step, 4)}
 
 
 def dry_run(args):
@@ -270,12 +300,13 @@ def dry_run(args):
         cs = [torch.zeros_like(c) for _ in range(world)]
         dist.all_gather(cs, c)
         assert all(float(v) == float(cs[0]) for v in cs), "ranks disagree on the stitched map"
+    comm = gather_diagnosis(P, ps, world, torch.device("cpu"), barrier, dt / args.steps * 1e3) if world > 1 else None
     if rank == 0:
         print(json.dumps({
             "metric": "patches/sec (DRY RUN of the multi-rank protocol on CPU tensors -- not a measurement)", "value": round(P * args.steps / dt, 3),
             "unit": "patches/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak" if N <= 4 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "dry_run": True, "rank_seconds": rank_s, "depth_shape": list(d.shape),
+            "dry_run": True, "rank_seconds": rank_s, "depth_shape": list(d.shape), "rccl": comm,
             "config": {"workload": f"DRY RUN: Depth-Anything-vits14 geometry {ps[0]}x{ps[1]}, {raw[0]}x{raw[1]} image, {split[0]}x{split[1]} tiles "
                                    f"({P} tiles, {P // N} per rank), gloo, torch stand-in ops",
                        "parallelism": f"patch-sharded x{N}, coarse+G2L replicated, gloo all_gather of tile depths" if N > 1 else "single process"}}), flush=True)
@@ -336,6 +367,36 @@ def kernel_source_sha():
     return h.hexdigest()[:12]
 
 
+def roofline_attention(dev):
+    """The second north-star kernel, timed live: the ViT split attention launch of the fine branch (pf_vit_attention_split3_v2, csrc/attn_split3.hip) at the
+    pass's shape -- 8 tiles x 16 heads x 1037 tokens, head_dim 64, real h / m / l planes of random float32 q / k / v in, chunk-major planes out.  Same accounting
+    as the dominant launch: USEFUL float32 FLOPs 4 B H S^2 64 (QK^T and PV, padding not counted) against 2500 / 6 TF/s (six bf16 MFMAs per product)."""
+    from patchfusion_amd.hip_ops import ops
+    B, S, Hh = 8, 1037, 16
+    D = Hh * 64
+    qkv = torch.randn(B * S, 3 * D, device=dev) * 0.5
+    q3 = torch.empty(3, B * S, 3 * D, dtype=torch.bfloat16, device=dev)
+    ops.split3(qkv, q3)
+    out = torch.empty(3, D // 32, B * S, 32, dtype=torch.bfloat16, device=dev)
+    for _ in range(3):
+        ops.vit_attention(q3, out, B, S, Hh)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 50
+    e0.record()
+    for _ in range(n):
+        ops.vit_attention(q3, out, B, S, Hh)
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    flops = 4.0 * B * Hh * S * S * 64
+    ach = flops / (ms * 1e-3) / 1e12
+    peak = PEAK_TFLOPS["bf16"] / 6.0
+    return {"kernel": "vit_attention_split3_pipe_kernel (32 x 32 x 16 bf16 MFMAs x 6 per float32 product, QK / softmax / PV of three consecutive 32-key blocks overlapped "
+                      f"in every wave; LDS-DMA K / V rings, transposing V reads) at {B} tiles x {Hh} heads x {S} tokens (24 such launches per tile batch)",
+            "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4), "us_per_launch": round(ms * 1e3, 1),
+            "flops_per_launch": flops}
+
+
 def roofline(dtype, dev, gemm_only=False):
     """Dominant kernel of the pass, timed live through the entry points the engine uses (HIP events on the launch stream).
 
@@ -361,7 +422,7 @@ def roofline(dtype, dev, gemm_only=False):
     pw = pk.pack_conv(w, torch.zeros(C), dtype=tdt).to(dev)
     peak = PEAK_TFLOPS[dtype]
     traffic = None
-    for rnd in ("r5", "r4", "r3"):        # the newest PMC summary measured on EXACTLY this kernel source
+    for rnd in ("r6", "r5", "r4", "r3"):        # the newest PMC summary measured on EXACTLY this kernel source
         try:
             with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_dominant_{dtype}.json")) as f:
                 j = json.load(f)
@@ -394,12 +455,16 @@ def roofline(dtype, dev, gemm_only=False):
             x = torch.randn(B, H, W, C, device=dev)
             y = torch.empty(B, H, W, C, device=dev)
             ms_layer = ops.conv(x, pw, y, pad=1, act="relu", _timed=5)
-        try:
-            with open(os.path.join(ROOT, "profiles", "r5_pmc_dominant_fp32.json")) as f:
-                j = json.load(f)
-            traffic = j["derived"]["traffic_bytes"] if (j.get("kernel_source_sha") == kernel_source_sha() and j.get("ws_cap_gb") == os.environ.get("PF_WS_CAP_GB", "2.5")) else None
-        except Exception:
-            traffic = None
+        traffic = None
+        for rnd in ("r6", "r5"):
+            try:
+                with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_dominant_fp32.json")) as f:
+                    j = json.load(f)
+                if j.get("kernel_source_sha") == kernel_source_sha() and abs(float(j.get("ws_cap_gb", -1)) - float(os.environ.get("PF_WS_CAP_GB", "2.5"))) < 1e-9:
+                    traffic = j["derived"]["traffic_bytes"]
+                    break
+            except Exception:
+                pass
         # the pipe this launch executes on is the bf16 MFMA, six instructions per useful float32 product: its ceiling for float32-grade work
         # is 2500 / 6 = 416.7 TF/s, and THAT is `peak` (round-3 review: pricing it against the 157.3 TF/s f32 MFMA peak, a pipe the kernel never
         # touches, printed 0.96 for a launch whose matrix pipe was 48 % busy)
@@ -420,8 +485,12 @@ def roofline(dtype, dev, gemm_only=False):
                 "executed_bf16": {"tflops": round(6 * ach, 1), "peak": PEAK_TFLOPS["bf16"], "frac": round(6 * ach / PEAK_TFLOPS["bf16"], 4)},
                 "layer": None if ms_layer is None else {
                     "what": f"whole layer = input transform (split planes) + batched GEMM + output transform/epilogue, 3x3 {C}->{C} @ {B}x{H}x{W} ({ns} tile windows)",
-                    "ms": round(ms_layer, 4), "transforms_ms": round(ms_layer - ns * ms, 4), "direct_conv_flops": direct_flops,
-                    "direct_conv_tflops_equivalent": round(direct_flops / (ms_layer * 1e-3) / 1e12, 2)}}
+                    # (GEMM share of the layer = the timed window scaled by tiles, Tall / T windows' worth: the last window is ragged -- round-5 advisor)
+                    "ms": round(ms_layer, 4), "transforms_ms": round(ms_layer - ms * Tall / T, 4), "direct_conv_flops": direct_flops,
+                    "direct_conv_tflops_equivalent": round(direct_flops / (ms_layer * 1e-3) / 1e12, 2),
+                    # the WHOLE layer against the same ceiling: its transform-domain multiply-adds (all Tall tiles) over its whole time, transforms included
+                    "frac": round(36 * 2.0 * Tall * C * C / (ms_layer * 1e-3) / 1e12 / peak, 4)},
+                "layer_frac": None if ms_layer is None else round(36 * 2.0 * Tall * C * C / (ms_layer * 1e-3) / 1e12 / peak, 4)}
     if pw.wino_up is not None and pk.winograd_applies(pw, B * H * W, 1, 1, "relu") and hip_ops._fused_wanted(B, H, W, pw):
         # round 3: the layer is ONE kernel (csrc/wino_fused.hip): its own multiply-adds = 36 transform points x 2 x T x C x C with
         # T = B * ceil(H/4) * ceil(W/4) output tiles (the padding tiles of the 4x8 super-tiles are not counted), priced against the

@@ -80,7 +80,8 @@ int pf_conv_winograd(const pf_conv_params* p, int m, const void* U, int u_rows, 
 int pf_conv_winograd_split3(const pf_conv_params* p, const void* U3, int u_rows, int u_kpad, void* V3, void* M, void* stream);
 /* the same layer `window` Winograd tiles at a time (window % 8 == 0; 0 = all tiles at once): V3 / M then are arenas for ONE window (3 x 36 x window x Cin
  * bf16, 36 x window x Cout float32) that every window reuses -- small windows keep the pair inside the 256 MB memory-side cache.  Tiles are independent:
- * identical results for every window. */
+ * identical results for every window.  With more than one window the output of window k is written before the input of window k + 1 (and its one-pixel
+ * halo) is read: x and y must NOT overlap then (PF_ERR_ARG); a residual may alias y (it is read at the pixels being written). */
 int pf_conv_winograd_split3_windowed(const pf_conv_params* p, const void* U3, int u_rows, int u_kpad, void* V3, void* M, long window, void* stream);
 
 /* FUSED Winograd F(4x4, 3x3) (csrc/wino_fused.hip): the same layers in ONE kernel -- the transformed input and the transform-domain

@@ -11,6 +11,7 @@
 // The transforms are exact small-integer / dyadic combinations evaluated in float32; the result differs from the direct
 // convolution only by rounding (measured per layer: m = 2 ~2.5x, m = 4 ~15x the rounding error of a direct f32 convolution,
 // DESIGN.md 4d).  Only float32 tensors; everything else stays on the direct kernels.
+#include <mutex>
 #include "pf_common.h"
 #include "../../include/pf_hip.h"
 
@@ -242,14 +243,27 @@ int run(const pf_conv_params* p, const float* U, int u_rows, int u_kpad, float* 
   return launch_ok();
 }
 
-// one event per device shared by every stream of the process (see run_split3)
+// one event per device shared by every stream of the process (see run_split3); created once per device under a once_flag (two host threads may enter together)
 hipEvent_t gemm_token() {
   static hipEvent_t ev[64] = {};
+  static std::once_flag once[64];
   int dev = 0;
   hipGetDevice(&dev);
-  hipEvent_t& e = ev[dev & 63];
-  if (!e) hipEventCreateWithFlags(&e, hipEventDisableTiming);
-  return e;
+  std::call_once(once[dev & 63], [&] { hipEventCreateWithFlags(&ev[dev & 63], hipEventDisableTiming); });
+  return ev[dev & 63];
+}
+
+// the three measurement switches of run_split3 (PF_W3_TGRID / PF_W3_GRID / PF_W3_TOKEN; all measured as "does not pay"), read from the environment ONCE
+struct W3Switches { int tgrid = 0, cap = 0; bool token = false; };
+const W3Switches& w3_switches() {
+  static W3Switches sw;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    if (const char* s = getenv("PF_W3_TGRID")) sw.tgrid = atoi(s);
+    if (const char* s = getenv("PF_W3_GRID")) sw.cap = atoi(s);
+    if (const char* s = getenv("PF_W3_TOKEN")) sw.token = s[0] == '1';
+  });
+  return sw;
 }
 
 // F(4x4,3x3) with the transform-domain GEMM in split precision: V is written as three bf16 planes, U3 = the three planes of G g G^T
@@ -260,16 +274,21 @@ int run_split3(const pf_conv_params* p, const void* U3, int u_rows, int u_kpad, 
   const long Tall = (long)p->B * TH * TW;
   if (Tall > 0x7fffffffL) return PF_ERR_ARG;
   if (window <= 0 || window > Tall) window = Tall;
-  // PF_W3_TGRID = n > 0: the transforms run RESIDENT on n CUs (n blocks of 512 threads walking the items) instead of flooding the chip
-  int tgrid = 0;
-  if (const char* s = getenv("PF_W3_TGRID")) tgrid = atoi(s);
+  // PF_W3_TGRID = n > 0: the transforms run RESIDENT on n CUs (n blocks of 512 threads walking the items) instead of flooding the chip.
   // Overlap of the HBM-bound transforms of one tile batch with the matrix-bound GEMM of the other (two streams; measured, off): the
   // persistent GEMM leaves CUs free (PF_W3_GRID blocks instead of one per CU) and, with PF_W3_TOKEN=1, the big GEMMs of ALL streams are chained
   // through one event in host-issue order, so that two capped GEMMs never compete for the same CUs.
-  int cap = 0;
-  if (const char* s = getenv("PF_W3_GRID")) cap = atoi(s);
-  hipEvent_t tok = nullptr;
-  if (const char* s = getenv("PF_W3_TOKEN")) if (s[0] == '1') tok = gemm_token();
+  const W3Switches& sw = w3_switches();
+  const int tgrid = sw.tgrid, cap = sw.cap;
+  hipEvent_t tok = sw.token ? gemm_token() : nullptr;
+  // With more than one window, window k's output is written before window k + 1's input (and its one-pixel halo across the seam) is read: x and y must
+  // not overlap (a single window reads all of x first, like the unwindowed sequence).  Refused instead of computing from half-overwritten input.
+  if (window < Tall) {
+    const char* xa = static_cast<const char*>(p->x);
+    const char* ya = static_cast<const char*>(p->y);
+    const long xb = ((long)p->B * p->H * p->W - 1) * p->x_ld * 4 + (long)p->Cin * 4, yb = ((long)p->B * p->H * p->W - 1) * p->y_ld * 4 + (long)p->Cout * 4;
+    if (xa < ya + yb && ya < xa + xb) return PF_ERR_ARG;
+  }
   // TILE WINDOWS (round 5): the layer's tiles go through the three steps `window` tiles at a time, all windows through the SAME V / M arena -- launches
   // of one stream are ordered.  Winograd tiles are independent, so the numbers do not depend on the window.
   for (long t0 = 0; t0 < Tall; t0 += window) {

@@ -212,20 +212,40 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
     def load_dict(self, dict):
         return self.load_state_dict(dict, strict=False)
 
-    def load_state_dict(self, *a, **k):
+    def _spec_tensors(self):
+        for name in self.spec:
+            mod = self
+            parts = name.split('.')
+            for q in parts[:-1]:
+                mod = mod._modules[q]
+            t = mod._parameters.get(parts[-1])
+            yield name, (t if t is not None else mod._buffers[parts[-1]])
+
+    def load_state_dict(self, state_dict, *a, **k):
+        if not getattr(self, "_params_freed", False):
+            self._engine = None
+            return super().load_state_dict(state_dict, *a, **k)
+        # free_parameters() released the checkpoint tensors: the incoming dict has to bring ALL of them back.  A partial dict (strict=False with one
+        # branch, the fusion-only `get_save_dict()` format, `_load_branch`) would leave the uncovered tensors at whatever the re-materialisation put
+        # there and the next forward would rebuild the engine from them -- wrong depth with no error (round-5 advisor, medium).  Such a call is refused
+        # and changes nothing: the engine built from the released tensors keeps serving forward().
+        missing = [n for n in self.spec if n not in state_dict]
+        if missing:
+            raise RuntimeError(f"PatchFusion.free_parameters() released the checkpoint tensors; load_state_dict() must now be given every tensor of the "
+                               f"model ({len(missing)} of {len(self.spec)} are missing, e.g. {missing[0]!r}).  Nothing was changed.")
+        dev = self._device
+        for name, t in self._spec_tensors():
+            e = self.spec[name]
+            t.data = torch.zeros(e.shape, dtype=e.dtype, device=dev)
+        try:
+            out = super().load_state_dict(state_dict, *a, **k)
+        except Exception:
+            for _, t in self._spec_tensors():                  # (a strict / shape error: back to the released state, old engine still valid)
+                t.data = torch.empty(0, dtype=t.dtype, device=t.device)
+            raise
+        self._params_freed = False
         self._engine = None
-        if getattr(self, "_params_freed", False):             # re-materialise the parameter storage that free_parameters() released
-            dev = self._device
-            for name, e in self.spec.items():
-                mod = self
-                parts = name.split('.')
-                for q in parts[:-1]:
-                    mod = mod._modules[q]
-                t = mod._parameters.get(parts[-1])
-                t = t if t is not None else mod._buffers[parts[-1]]
-                t.data = torch.zeros(e.shape, dtype=e.dtype, device=dev)
-            self._params_freed = False
-        return super().load_state_dict(*a, **k)
+        return out
 
     def _apply(self, fn, *a, **k):
         if getattr(self, "_params_freed", False):

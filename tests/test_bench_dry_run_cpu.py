@@ -36,3 +36,7 @@ def test_scale_command_line_dry_run(n):
     assert j["depth_shape"] == [1, 1, grid[0] * 112, grid[1] * 154]
     assert abs(j["ms_per_step"] - max(j["rank_seconds"]) * 1e3) < 1.0 and j["value"] > 0
     assert j["scaling"] == ("strong" if n == 8 else "weak")
+    # the communicator's self-diagnosis (bench.gather_diagnosis; "rccl" on GPUs, gloo here): its size after a real collective, rows in tile order, the gather's own time
+    c = j["rccl"]
+    assert c["ranks"] == n and c["backend"] == "gloo" and c["rows_in_tile_order"] is True and c["tile_gather_ms"] > 0
+    assert c["gathered_shape"] == [grid[0] * grid[1], 112, 154]

@@ -140,6 +140,38 @@ def test_load_dict_and_get_save_dict_like_tools_test_py(tiny):
     assert torch.equal(m2.state_dict()["fusion_conv_list.0.weight"], sd["fusion_conv_list.0.weight"])
 
 
+def test_partial_checkpoint_after_free_parameters_is_refused_and_changes_nothing(tiny):
+    """round-5 advisor (medium): after free_parameters() a load_state_dict() that does not cover every tensor (strict=False with the fusion-only
+    get_save_dict() format, one branch through _load_branch) used to zero-fill the uncovered tensors, clear the flag and let the next forward rebuild the
+    engine from zeros.  Now it raises, the module stays in the released state and the live engine keeps producing the same numbers; a strict load that
+    fails (unexpected key) also leaves the released state; a complete dict restores the module."""
+    cfg, sd, _, img = tiny
+    m = PatchFusion(cfg, compute_dtype="fp32", ops=fake_ops).eval()
+    m.load_state_dict(sd, strict=True)
+    lr = m.resizer(img)
+    with torch.no_grad():
+        d0, _ = m(mode="infer", image_lr=lr, image_hr=img, cai_mode="m1", process_num=2)
+    save = m.get_save_dict()
+    m.free_parameters()
+    engine = m._engine
+    with pytest.raises(RuntimeError, match="must now be given every tensor"):
+        m.load_dict(save)                                           # the reference's own strict=False helper with a fusion-only checkpoint
+    with pytest.raises(RuntimeError, match="must now be given every tensor"):
+        m._load_branch("coarse_branch.", {k[len("coarse_branch."):]: v for k, v in sd.items() if k.startswith("coarse_branch.")})
+    assert m._params_freed and m._engine is engine and sum(p.numel() for p in m.parameters()) == 0
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(dict(sd, not_a_key=torch.zeros(1)), strict=True)
+    assert m._params_freed and m._engine is engine and sum(p.numel() for p in m.parameters()) == 0
+    with torch.no_grad():
+        d1, _ = m(mode="infer", image_lr=lr, image_hr=img, cai_mode="m1", process_num=2)
+    assert torch.equal(d0, d1)
+    m.load_state_dict(sd, strict=True)
+    assert not m._params_freed and m._engine is None and len(m.state_dict()) == len(sd)
+    with torch.no_grad():
+        d2, _ = m(mode="infer", image_lr=lr, image_hr=img, cai_mode="m1", process_num=2)
+    assert torch.equal(d0, d2)
+
+
 def test_plain_dict_config_never_loads_branch_checkpoints(tiny):
     """HF path (patchfusion.py:70-78): config.json written by tools/convert_huggingface.py carries load_branch=true and
     local ./work_dir paths; a plain-dict config must force load_branch=False instead of torch.load-ing them."""

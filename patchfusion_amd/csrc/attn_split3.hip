@@ -388,12 +388,18 @@ __global__ __launch_bounds__(256, 2) void vit_attention_split3_pipe_kernel(const
     }
   }
   const int b = bh / Hh, h = bh - b * Hh;
-  const int q0 = qb * 128 + wave * 32;
+  const int NB = (S + 31) / 32;
+  // KEY-SPLIT tail blocks: the last query block of S = 1037 holds 13 queries -- one wave's worth.  Run as it stands that block takes as long as a full one (a
+  // wave's chain over all 33 key blocks: 67 of 79 us, profiles/r6_attention_blocks.md) with three waves idle, and the 128 of them cost the launch a third
+  // round of blocks.  Instead all four waves take the SAME (at most 32) queries and wave w the key blocks jb = w (mod 4): in step j it runs the one stage
+  // whose block is its own (QK(j + 1), softmax(j) or PV(j - 1)), so a step of the block costs one stage instead of three; the four partial (reference
+  // exponent, sum, O) sets are merged through LDS at the end (flash-decoding style: O = sum_w O_w 2^(m_w - m), l likewise).
+  const bool ksplit = S - qb * 128 <= 32 && NB >= 8;
+  const int q0 = qb * 128 + (ksplit ? 0 : wave * 32);
   const bool has_q = q0 < S;
   const int D = Hh * 64;
   const long rs = 3L * D;
   const bf16_t* base = qkv3 + (long)b * S * rs + h * 64;
-  const int NB = (S + 31) / 32;
 
   // ---- DMA roles: wave w moves pieces 3 w .. 3 w + 2 of a block (piece p = plane p >> 2, keys 8 (p & 3) .. + 7); lane L = row L >> 3, LDS chunk L & 7
   const unsigned rs_b = (unsigned)(rs * 2);
@@ -655,42 +661,88 @@ __global__ __launch_bounds__(256, 2) void vit_attention_split3_pipe_kernel(const
   using F = std::false_type;
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
-  // slot byte offsets: K slot of step j = ((j + 1) % 3) PB, V slot = ((j + 2) % 3) PB
-  step(T{}, F{}, F{}, F{}, P1{}, 0, 0, 0);                                           // j = -1: QK(0)
-  turn(-1, 0, PB_BYTES);
-  if (NB > 1) step(T{}, T{}, F{}, F{}, P0{}, PB_BYTES, 0, 0);                        // j = 0: QK(1), softmax(0)
-  else step(F{}, T{}, T{}, F{}, P0{}, 0, 0, S);                                      //        (a single key block: softmax(0) masked)
-  turn(0, PB_BYTES, 2 * PB_BYTES);
-  int ks = 2 * PB_BYTES, vs = 0;                                                     // step 1: K slot 2, V slot 0
-  int j = 1;
-  for (; j + 1 <= NB - 2; j += 2) {
-    step(T{}, T{}, F{}, T{}, P1{}, ks, vs, 0);
-    turn(j, ks, vs);
-    ks = ks == 2 * PB_BYTES ? 0 : ks + PB_BYTES;
-    vs = vs == 2 * PB_BYTES ? 0 : vs + PB_BYTES;
-    step(T{}, T{}, F{}, T{}, P0{}, ks, vs, 0);
-    turn(j + 1, ks, vs);
-    ks = ks == 2 * PB_BYTES ? 0 : ks + PB_BYTES;
-    vs = vs == 2 * PB_BYTES ? 0 : vs + PB_BYTES;
+  if (!ksplit) {
+    // slot byte offsets: K slot of step j = ((j + 1) % 3) PB, V slot = ((j + 2) % 3) PB
+    step(T{}, F{}, F{}, F{}, P1{}, 0, 0, 0);                                           // j = -1: QK(0)
+    turn(-1, 0, PB_BYTES);
+    if (NB > 1) step(T{}, T{}, F{}, F{}, P0{}, PB_BYTES, 0, 0);                        // j = 0: QK(1), softmax(0)
+    else step(F{}, T{}, T{}, F{}, P0{}, 0, 0, S);                                      //        (a single key block: softmax(0) masked)
+    turn(0, PB_BYTES, 2 * PB_BYTES);
+    int ks = 2 * PB_BYTES, vs = 0;                                                     // step 1: K slot 2, V slot 0
+    int j = 1;
+    for (; j + 1 <= NB - 2; j += 2) {
+      step(T{}, T{}, F{}, T{}, P1{}, ks, vs, 0);
+      turn(j, ks, vs);
+      ks = ks == 2 * PB_BYTES ? 0 : ks + PB_BYTES;
+      vs = vs == 2 * PB_BYTES ? 0 : vs + PB_BYTES;
+      step(T{}, T{}, F{}, T{}, P0{}, ks, vs, 0);
+      turn(j + 1, ks, vs);
+      ks = ks == 2 * PB_BYTES ? 0 : ks + PB_BYTES;
+      vs = vs == 2 * PB_BYTES ? 0 : vs + PB_BYTES;
+    }
+    if (j <= NB - 2) {                                                                 // one more steady step (odd j)
+      step(T{}, T{}, F{}, T{}, P1{}, ks, vs, 0);
+      turn(j, ks, vs);
+      ks = ks == 2 * PB_BYTES ? 0 : ks + PB_BYTES;
+      vs = vs == 2 * PB_BYTES ? 0 : vs + PB_BYTES;
+      ++j;
+    }
+    // j == max(NB - 1, 1): the last block's softmax (masked) beside PV(NB - 2), then PV(NB - 1); nothing is fetched any more
+    const int rem = S - (NB - 1) * 32;
+    if (NB > 1) {
+      if (j & 1) step(F{}, T{}, T{}, T{}, P1{}, ks, vs, rem);
+      else step(F{}, T{}, T{}, T{}, P0{}, ks, vs, rem);
+      vs = vs == 2 * PB_BYTES ? 0 : vs + PB_BYTES;
+      ++j;
+    }
+    barrier_all();                                          // V(NB - 1) of EVERY wave has landed (and every DMA, before the block may exit)
+    if (j & 1) step(F{}, F{}, F{}, T{}, P1{}, 0, vs, 0);
+    else step(F{}, F{}, F{}, T{}, P0{}, 0, vs, 0);
+  } else {
+    // one stage per wave and step (see ksplit above); the ring protocol (turn) is the same for every wave
+    const int remk = S - (NB - 1) * 32;
+    int ksj = 0, vsj = PB_BYTES;                                                       // j = -1: K slot 0, V slot 1
+    // (a wave's stages of one block are three consecutive steps and its next block is four steps later: ONE S^T and ONE P register set suffice -- QK writes
+    //  sA (parity 1), the softmax reads sA and writes pA (parity 0), PV reads pA (parity 1) -- so the only instantiation this path adds is the bare softmax)
+    for (int jj = -1; jj <= NB; ++jj) {
+      if (((jj + 1 - wave) & 3) == 0 && jj + 1 < NB) step(T{}, F{}, F{}, F{}, P1{}, ksj, vsj, 0);            // QK of my block jj + 1
+      else if (((jj - wave) & 3) == 0 && jj >= 0 && jj < NB) {                                                // softmax of my block jj
+        if (jj == NB - 1) step(F{}, T{}, T{}, F{}, P0{}, ksj, vsj, remk);
+        else step(F{}, T{}, F{}, F{}, P0{}, ksj, vsj, 0);
+      } else if (((jj - 1 - wave) & 3) == 0 && jj >= 1 && jj - 1 < NB) step(F{}, F{}, F{}, T{}, P1{}, ksj, vsj, 0);   // PV of my block jj - 1
+      if (jj <= NB - 2) turn(jj, ksj, vsj);
+      else if (jj == NB - 1) barrier_all();
+      ksj = ksj == 2 * PB_BYTES ? 0 : ksj + PB_BYTES;
+      vsj = vsj == 2 * PB_BYTES ? 0 : vsj + PB_BYTES;
+    }
+    // merge: waves 1..3 park (reference exponent, sum, O) in LDS (the rings are idle: every DMA landed before the last barrier), wave 0 folds them in
+    __syncthreads();
+    float* park = reinterpret_cast<float*>(smem);
+    if (wave > 0) {
+      float* pw = park + (wave - 1) * 34 * 64 + lane;
+      pw[0] = m_run;
+      pw[64] = l_run;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pw[(2 + t * 16 + i) * 64] = o[t][i];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll 1
+    for (int w = 0; w < 3; ++w) {
+      const float* pw = park + w * 34 * 64 + lane;
+      const float mw = pw[0], lw = pw[64];
+      const float mn = fmaxf(m_run, mw);
+      const float f0 = __builtin_amdgcn_exp2f(m_run - mn), fw = __builtin_amdgcn_exp2f(mw - mn);      // (a wave without key blocks parks -inf, 0, 0: fw = 0)
+      l_run = l_run * f0 + lw * fw;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[t][i] = o[t][i] * f0 + pw[(2 + t * 16 + i) * 64] * fw;
+      m_run = mn;
+    }
   }
-  if (j <= NB - 2) {                                                                 // one more steady step (odd j)
-    step(T{}, T{}, F{}, T{}, P1{}, ks, vs, 0);
-    turn(j, ks, vs);
-    ks = ks == 2 * PB_BYTES ? 0 : ks + PB_BYTES;
-    vs = vs == 2 * PB_BYTES ? 0 : vs + PB_BYTES;
-    ++j;
-  }
-  // j == max(NB - 1, 1): the last block's softmax (masked) beside PV(NB - 2), then PV(NB - 1); nothing is fetched any more
-  const int rem = S - (NB - 1) * 32;
-  if (NB > 1) {
-    if (j & 1) step(F{}, T{}, T{}, T{}, P1{}, ks, vs, rem);
-    else step(F{}, T{}, T{}, T{}, P0{}, ks, vs, rem);
-    vs = vs == 2 * PB_BYTES ? 0 : vs + PB_BYTES;
-    ++j;
-  }
-  barrier_all();                                          // V(NB - 1) of EVERY wave has landed (and every DMA, before the block may exit)
-  if (j & 1) step(F{}, F{}, F{}, T{}, P1{}, 0, vs, 0);
-  else step(F{}, F{}, F{}, T{}, P0{}, 0, vs, 0);
 
   TL_MARK(10);                                           // [10] final wait
   if (!has_q) return;

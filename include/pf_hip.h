@@ -110,6 +110,14 @@ int pf_conv_winograd_fused_timed(const pf_conv_params* p, const void* up, int nn
  * one 128 x 128 tile per block, or -- from two rounds of tiles on -- a PERSISTENT kernel (one block per CU walks its tiles) with 128 x 128 tiles
  * on a three-slot LDS ring or 192 x 192 tiles on a two-slot ring, whichever costs fewer rounds x tile cost. */
 int pf_gemm_split3(const pf_conv_params* p, void* stream);
+/* The same split-precision product for a 1x1 convolution / linear layer whose ACTIVATIONS are plain float32 (round 6; replaces pf_conv's f32-MFMA
+ * route for the 1x1 layers of the DPT / metric-bins heads -- external/zoedepth/models/layers/localbins_layers.py:99-117, attractor.py:156-161,
+ * base_models/dpt_dinov2/blocks.py (out_conv / projections) -- and the G2L Swin linears, estimator/models/blocks/swin_layers.py:120-128,133-164):
+ * `p` exactly as for pf_conv with KH = KW = 1, stride 1, pad 0, shuffle 1, dtype PF_DTYPE_F32 (x float32 [M][x_ld], x_ld % 4 == 0, Cin % 32 == 0;
+ * bias / scale / res / res2 / y float32; act, relu_in as pf_conv; p->w is not read); w3 = the weight's three bf16 planes, CHUNK-MAJOR
+ * [3][Cin/32][w3_rows][32] (packing.pack_conv_split3(kmajor=True); w3_rows % 16 == 0, >= Cout).  The kernel splits x in its loader (three LDS
+ * planes per K chunk), so no producer has to change; error against float64 = pf_gemm_split3's (tests/op_checks.py conv1x1_split3). */
+int pf_conv1x1_split3(const pf_conv_params* p, const void* w3, int w3_rows, void* stream);
 /* the same call with the persistent kernels capped at `grid_cap` blocks (0 = one per CU): the CUs left over run the kernels of OTHER streams
  * (the HBM-bound Winograd transforms of the other tile batch) beside the matrix-bound GEMM */
 int pf_gemm_split3_ex(const pf_conv_params* p, int grid_cap, void* stream);

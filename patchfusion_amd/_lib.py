@@ -59,6 +59,7 @@ SIGNATURES = {
     "pf_conv_winograd_split3_windowed": [C.POINTER(ConvParams), vp, ci, ci, vp, vp, C.c_long, vp],
     "pf_gemm_split3": [C.POINTER(ConvParams), vp],
     "pf_gemm_split3_ex": [C.POINTER(ConvParams), ci, vp],
+    "pf_conv1x1_split3": [C.POINTER(ConvParams), vp, ci, vp],
     "pf_gemm_split3_timed": [C.POINTER(ConvParams), ci, C.POINTER(cf), vp],
     "pf_gemm_bf16_pp": [C.POINTER(ConvParams), vp],
     "pf_split3": [vp, ci, vp, ci, cl, cl, ci, vp],

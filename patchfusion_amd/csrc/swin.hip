@@ -3,6 +3,8 @@
 // head_dim is tiny here (2..32) -- MFMA-hostile -- so the attention runs on the VALU with K/V of one
 // (window, head) in LDS (broadcast reads) and one query per thread; it is HBM/LDS bound.
 #include "pf_common.h"
+#include <cstdlib>
+#include <mutex>
 #include "../../include/pf_hip.h"
 
 namespace {
@@ -123,6 +125,148 @@ __global__ __launch_bounds__(192) void swin_window_attention_kernel(const T* __r
   for (int d = 0; d < HD; ++d) Elem<T>::st(dst + d, acc[d] * inv);
 }
 
+
+// Window attention on the f32 matrix pipe (round 6).  A block owns one window and one 32-channel slab of
+// the qkv rows (32 / HD heads): q (pre-scaled), k, v of the slab are staged with whole-line reads into LDS
+// rows of 36 floats (the 16 x 4 fragment reads of v_mfma_f32_16x16x4_f32 then touch 64 distinct banks).  A
+// wave takes (16 queries, head) items: S^T = K Q^T as nine 16-key tiles (so that a lane keeps ONE query's
+// scores: keys 16 kt + 4 (lane / 16) + i, query lane % 16), bias / shift mask / softmax in registers with two
+// cross-lane steps, then O^T = V^T P^T where MFMA i of key tile kt contracts over exactly the keys its B
+// registers hold.  O goes back through the item's own q block in LDS and leaves with whole-line stores.
+// reference: estimator/models/blocks/swin_layers.py:133-164 (WindowAttention.forward).
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void swin_window_attention_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                            const float* __restrict__ bias_table, int Hp, int Wp,
+                                                                            int C, int heads, int shift) {
+  constexpr int NH = 32 / HD;   // heads in a 32-channel slab
+  constexpr int LD = 36;        // LDS row stride (floats)
+  constexpr int ND = HD > 16 ? HD / 16 : 1;
+  extern __shared__ __attribute__((aligned(16))) char swin_lds[];
+  float* Qs = reinterpret_cast<float*>(swin_lds);
+  float* Ks = Qs + WTOK * LD;
+  float* Vs = Ks + WTOK * LD;
+  int* koff = reinterpret_cast<int*>(Vs + WTOK * LD);        // per token: -4 (23 y + x), the byte step into a head's bias row
+  int* region = koff + WTOK;                                 // per token: region of the shift mask
+  float* bias = reinterpret_cast<float*>(region + WTOK);     // [NH][529]
+  const int win = blockIdx.x, slab = blockIdx.y;
+  const int nwx = Wp / WIN, nwy = Hp / WIN;
+  const int wloc = win % (nwx * nwy);
+  const int wy = wloc / nwx, wx = wloc % nwx;
+  // only the last window row / column of a shifted layer holds more than one mask region (swin_layers.py:228-246)
+  const bool masked = shift > 0 && (wy == nwy - 1 || wx == nwx - 1);
+  const int t = threadIdx.x;
+  const long row0 = (long)win * WTOK;
+  constexpr float scale = HD == 2 ? 0.70710678118654752f : HD == 4 ? 0.5f : HD == 8 ? 0.35355339059327376f : HD == 16 ? 0.25f : 0.17677669529663688f;
+  for (int idx = t; idx < WTOK * 8; idx += NW * 64) {
+    const int row = idx >> 3, c4 = (idx & 7) * 4;
+    const float* base = qkv + (row0 + row) * 3 * C + slab * 32 + c4;
+    float4 q = *reinterpret_cast<const float4*>(base);
+    const float4 k = *reinterpret_cast<const float4*>(base + C);
+    const float4 v = *reinterpret_cast<const float4*>(base + 2 * C);
+    q.x *= scale; q.y *= scale; q.z *= scale; q.w *= scale;
+    *reinterpret_cast<float4*>(Qs + row * LD + c4) = q;
+    *reinterpret_cast<float4*>(Ks + row * LD + c4) = k;
+    *reinterpret_cast<float4*>(Vs + row * LD + c4) = v;
+  }
+  for (int i = t; i < NH * 529; i += NW * 64) bias[i] = bias_table[(i % 529) * heads + slab * NH + i / 529];
+  if (t < WTOK) {
+    const int sy = wy * WIN + t / WIN, sx = wx * WIN + t % WIN;
+    const int hid = sy < Hp - WIN ? 0 : (sy < Hp - shift ? 1 : 2);
+    const int wid = sx < Wp - WIN ? 0 : (sx < Wp - shift ? 1 : 2);
+    koff[t] = -4 * ((t / WIN) * (2 * WIN - 1) + t % WIN);
+    region[t] = shift > 0 ? hid * 3 + wid : 0;
+  }
+  __syncthreads();
+  const int lane = t & 63, wave = t >> 6;
+  const int r = lane & 15, c = lane >> 4;
+  for (int item = wave; item < 9 * NH; item += NW) {
+    const int qt = item % 9, hl = item / 9;
+    const int ch = hl * HD;
+    f32x4 acc[9];
+#pragma unroll
+    for (int kt = 0; kt < 9; ++kt) acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* Qb = Qs + (qt * 16 + r) * LD + ch + c;
+    const float* Kb = Ks + r * LD + ch + c;
+#pragma unroll
+    for (int j = 0; j < (HD + 3) / 4; ++j) {
+      const bool dok = HD >= 4 || c < HD;        // HD = 2: only k = 0, 1 carry data
+      const float b = dok ? Qb[4 * j] : 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 9; ++kt) {
+        const float a = dok ? Kb[kt * 16 * LD + 4 * j] : 0.f;
+        acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[kt], 0, 0, 0);
+      }
+    }
+    const int tq = qt * 16 + r;
+    // index(i, j) = (yi - yj + 11) * 23 + xi - xj + 11: the query's part as a byte address, the key's part from koff
+    const char* bh = reinterpret_cast<const char*>(bias + hl * 529 + (WIN - 1) * (2 * WIN - 1) + WIN - 1) - koff[tq];
+    const int myreg = region[tq];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 9; ++kt) {
+      const int4 ko = *reinterpret_cast<const int4*>(koff + kt * 16 + 4 * c);
+      const int kk[4] = {ko.x, ko.y, ko.z, ko.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[kt][i] += *reinterpret_cast<const float*>(bh + kk[i]);
+      if (masked) {
+        const int4 rg = *reinterpret_cast<const int4*>(region + kt * 16 + 4 * c);
+        const int rr[4] = {rg.x, rg.y, rg.z, rg.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (rr[i] != myreg) acc[kt][i] += -100.0f;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mx = fmaxf(mx, acc[kt][i]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // e^(s - mx) on the hardware exp2 (1 ulp): the arguments are <= 0, the softmax sums 144 of them
+    constexpr float LOG2E = 1.44269504088896340736f;
+    const float mxl = mx * LOG2E;
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 9; ++kt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[kt][i], LOG2E, -mxl));
+        acc[kt][i] = pe;
+        l += pe;
+      }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) {
+      f32x4 o0 = f32x4{0.f, 0.f, 0.f, 0.f}, o1 = o0;       // two chains: a dependent f32 MFMA waits 40 cycles, an independent one 32
+      const bool dok = dt * 16 + r < HD;
+      const float* Vb = Vs + (4 * c) * LD + ch + dt * 16 + r;
+#pragma unroll
+      for (int kt = 0; kt < 9; ++kt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float a = dok ? Vb[(kt * 16 + i) * LD] : 0.f;
+          if ((kt * 4 + i) & 1) o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, acc[kt][i], o1, 0, 0, 0);
+          else o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, acc[kt][i], o0, 0, 0, 0);
+        }
+      // O^T[d = 16 dt + 4 c + i][query r] -> the item's own q block (this wave is the only reader / writer of it)
+      if (dt * 16 + 4 * c < HD) {
+        float* dst = Qs + (qt * 16 + r) * LD + ch + dt * 16 + 4 * c;
+        if constexpr (HD >= 4) {
+          *reinterpret_cast<float4*>(dst) = make_float4((o0[0] + o1[0]) * inv, (o0[1] + o1[1]) * inv, (o0[2] + o1[2]) * inv, (o0[3] + o1[3]) * inv);
+        } else {
+          dst[0] = (o0[0] + o1[0]) * inv;
+          dst[1] = (o0[1] + o1[1]) * inv;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int idx = t; idx < WTOK * 8; idx += NW * 64) {
+    const int row = idx >> 3, c4 = (idx & 7) * 4;
+    *reinterpret_cast<float4*>(out + (row0 + row) * C + slab * 32 + c4) = *reinterpret_cast<const float4*>(Qs + row * LD + c4);
+  }
+}
+
 template <typename T>
 __global__ void swin_unpartition_add_kernel(const T* __restrict__ proj, const T* __restrict__ sc, int s_ld, T* __restrict__ y,
                                             int y_ld, int B, int H, int W, int C, int shift) {
@@ -184,6 +328,29 @@ int launch_wattn(const T* qkv, T* out, const float* bt, int B, int Hp, int Wp, i
   return ok();
 }
 
+
+// f32 rows with whole 32-channel slabs: the matrix-pipe kernel (PF_SWIN_MFMA=0 keeps the VALU kernel, for A/B and checks)
+template <int HD>
+int launch_wattn_mfma(const float* qkv, float* out, const float* bt, int B, int Hp, int Wp, int C, int heads, int shift, hipStream_t st) {
+  constexpr int NW = 9;
+  constexpr int NH = 32 / HD;
+  const int lds = (3 * WTOK * 36 + NH * 529 + 2 * WTOK) * 4;
+  static std::once_flag once;
+  static bool attr_ok = false;
+  std::call_once(once, [&] {
+    attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(swin_window_attention_mfma_kernel<HD, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+  });
+  if (!attr_ok) return PF_ERR_LAUNCH;
+  dim3 grid(B * (Hp / WIN) * (Wp / WIN), C / 32);
+  hipLaunchKernelGGL((swin_window_attention_mfma_kernel<HD, NW>), grid, dim3(NW * 64), lds, st, qkv, out, bt, Hp, Wp, C, heads, shift);
+  return ok();
+}
+
+inline bool swin_mfma_enabled() {          // (read per call: 24 launches per image; lets one process A/B the two kernels)
+  const char* e = getenv("PF_SWIN_MFMA");
+  return !(e && e[0] == '0');
+}
+
 }  // namespace
 
 #define ST(s) reinterpret_cast<hipStream_t>(s)
@@ -205,6 +372,19 @@ extern "C" int pf_swin_window_attention(const void* qkv, void* out, const float*
                                         int heads, int shift, int dtype, void* stream) {
   if (!qkv || !out || !bias_table || Hp % WIN || Wp % WIN || C % heads) return PF_ERR_ARG;
   if (dtype == PF_DTYPE_BF16) return launch_wattn<bf16_t>((const bf16_t*)qkv, (bf16_t*)out, bias_table, B, Hp, Wp, C, heads, shift, ST(stream));
+  const int hd = C / heads;
+  if (C % 32 == 0 && swin_mfma_enabled()) {
+    const float* q = (const float*)qkv;
+    float* o = (float*)out;
+    switch (hd) {
+      case 2: return launch_wattn_mfma<2>(q, o, bias_table, B, Hp, Wp, C, heads, shift, ST(stream));
+      case 4: return launch_wattn_mfma<4>(q, o, bias_table, B, Hp, Wp, C, heads, shift, ST(stream));
+      case 8: return launch_wattn_mfma<8>(q, o, bias_table, B, Hp, Wp, C, heads, shift, ST(stream));
+      case 16: return launch_wattn_mfma<16>(q, o, bias_table, B, Hp, Wp, C, heads, shift, ST(stream));
+      case 32: return launch_wattn_mfma<32>(q, o, bias_table, B, Hp, Wp, C, heads, shift, ST(stream));
+      default: break;
+    }
+  }
   return launch_wattn<float>((const float*)qkv, (float*)out, bias_table, B, Hp, Wp, C, heads, shift, ST(stream));
 }
 

@@ -98,6 +98,20 @@ def _bf16_pp_enabled():
     return _env("PF_BF16_PP", "0") == "1"
 
 
+def _conv1x1_split3_wanted(M, pw):
+    """float32 1x1 layer through csrc/conv1x1_split3.hip (64 x 128 tiles, two blocks per CU) instead of the f32-MFMA implicit GEMM?  PF_CONV1X1_SPLIT3:
+    0 = never, 2 = wherever the planes exist, 1 (default) = the measured rule (profiles/r6_conv1x1_split3.md: 1.16-1.47x on every layer of the pass
+    with at least 64 input and 64 output channels and two tiles per CU; 0.7-1.1x on the 32-channel layers, where a 128-wide channel tile
+    multiplies zeros and a K chunk is the whole layer)."""
+    mode = _env("PF_CONV1X1_SPLIT3", "1")
+    if mode == "0":
+        return False
+    if mode == "2":
+        return True
+    tiles = -(-M // 64) * -(-pw.cout // 128)
+    return tiles >= 512 and pw.cout >= 64 and pw.cin >= 64
+
+
 def _split3_three_step(pw):
     """does the three-step form of this layer run its GEMM in split precision? (filters packed as three planes and PF_WINO_SPLIT3 != 0)"""
     return pw.wino_u3 is not None and _env("PF_WINO_SPLIT3", "1") != "0"
@@ -234,6 +248,10 @@ class HipOps:
                 B * H * W >= 2048 and pw.cin % 64 == 0 and pw.cin >= 512 and pw.cout >= 512 and _bf16_pp_enabled()):
             # bf16 linear layers with many token rows (ViT blocks, DPT projections): 256 x 128 ping-pong tiles (csrc/gemm_split3.hip, PLAIN)
             return "pp", p, None
+        if (pw.w3 is not None and x4.dtype == torch.float32 and f32_io and stride == 1 and pad == 0 and s == 1 and not direct and
+                _conv1x1_split3_wanted(B * H * W, pw)):
+            # float32 1x1 layers with enough tokens: split-precision product on the bf16 matrix cores, x split in the kernel's loader
+            return "s3_1x1", p, (_p(pw.w3), pw.w3.shape[2])
         wino = winograd_applies(pw, B * H * W, stride, pad, act) and not direct
         if wino and pw.wino_up is not None and _fused_wanted(B, H, W, pw) and _L.pf_conv_winograd_fused_supported(C.byref(p)):
             # fused F(4x4,3x3): one kernel, no V / M workspaces (csrc/wino_fused.hip)
@@ -256,6 +274,8 @@ class HipOps:
     def _conv_exec(route, p, extra, device):
         if route == "direct":
             check(_L.pf_conv(C.byref(p), _stream()), "pf_conv")
+        elif route == "s3_1x1":
+            check(_L.pf_conv1x1_split3(C.byref(p), extra[0], extra[1], _stream()), "pf_conv1x1_split3")
         elif route == "fused":
             check(_L.pf_conv_winograd_fused(C.byref(p), extra[0], extra[1], extra[2], _stream()), "pf_conv_winograd_fused")
         elif route == "wino3":

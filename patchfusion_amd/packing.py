@@ -35,6 +35,7 @@ class PackedConv:
     wino_u: Optional[torch.Tensor] = None   # [(m+2)^2, rows, Kpad1] float32: G g G^T, each plane packed like a 1x1 weight
     wino_up: Optional[torch.Tensor] = None  # m = 4 only: the same filters in the fragment order of the fused kernel (winograd_filters_fused)
     wino_u3: Optional[torch.Tensor] = None  # m = 4 only: wino_u as the three bf16 planes of the split-precision GEMM, chunk-major [3, 36, Kpad1/32, rows, 32]
+    w3: Optional[torch.Tensor] = None       # float32 1x1 layers with cin % 32 == 0: the weight's three bf16 planes, chunk-major [3, cin/32, rows, 32] (csrc/conv1x1_split3.hip)
 
     def to(self, device):
         self.w = self.w.to(device)
@@ -44,6 +45,8 @@ class PackedConv:
             self.wino_up = self.wino_up.to(device)
         if self.wino_u3 is not None:
             self.wino_u3 = self.wino_u3.to(device)
+        if self.w3 is not None:
+            self.w3 = self.w3.to(device)
         if self.bias is not None:
             self.bias = self.bias.to(device)
         if self.scale is not None:
@@ -199,7 +202,19 @@ def pack_conv(weight, bias=None, *, dtype, cin_map=None, cin_total=None, scale=N
            if (wm == 4 and winograd_split3_enabled()) else None)
     if wm == 0 and scale is None and winograd_fused_only_eligible(cout_store, cin_total, KH, KW, dtype):
         wm, wup = 4, winograd_filters_fused(wk)                   # fused kernel only (wino_u stays None: no three-step form)
-    return PackedConv(wp.to(dtype).contiguous(), bp, sp, KH, KW, cin_total, cout_store, cout, korder=korder, wino_m=wm, wino_u=wu, wino_up=wup, wino_u3=wu3)
+    # float32 1x1 layers: the weight again as three bf16 planes for the split-precision 1x1 kernel that splits its float32 activations itself
+    # (csrc/conv1x1_split3.hip; hip_ops routes by token count).  1.5x the float32 weight's bytes; these layers are small.
+    w3 = (rows_to_kmajor(torch.stack(split3(wk.reshape(rows, cin_total))).contiguous())
+          if (dtype == torch.float32 and KH == 1 and KW == 1 and cin_total % 32 == 0 and conv1x1_split3_enabled()) else None)
+    return PackedConv(wp.to(dtype).contiguous(), bp, sp, KH, KW, cin_total, cout_store, cout, korder=korder, wino_m=wm, wino_u=wu, wino_up=wup, wino_u3=wu3,
+                      w3=w3)
+
+
+def conv1x1_split3_enabled():
+    """float32 1x1 convolutions / linears through the split-precision kernel with the in-loader split (csrc/conv1x1_split3.hip)?  PF_CONV1X1_SPLIT3=0 / 1,
+    default on (read at pack time: the planes are only packed when it is on)"""
+    import os
+    return os.environ.get("PF_CONV1X1_SPLIT3", "1") != "0"
 
 
 def split3(x):

@@ -713,6 +713,72 @@ def gemm_split3_persist(dt):
     return worst, 2e-6, "; ".join(info)
 
 
+def conv1x1_split3(dt):
+    """float32 1x1 convolution through the split-precision kernel that splits its activations in the loader (csrc/conv1x1_split3.hip, forced with
+    PF_CONV1X1_SPLIT3=2) against float64 on the same float32 operands, beside the f32-MFMA kernel's own error (`_direct`): ragged token counts,
+    1 .. 32 K chunks, channel counts off the 128-wide tile, channel-slice views on both sides, every epilogue option, ReLU on the input, and
+    operands spanning twelve decades.  The split route must be float32-grade: no worse than 2e-6 of max|ref|."""
+    import os
+    o = hip()
+    g = torch.Generator().manual_seed(171)
+    os.environ["PF_CONV1X1_SPLIT3"] = "2"
+    _switches_changed()
+    worst, info = 0.0, []
+    try:
+        for (B, H, W, K, N, act, relu_in, res, res2, scale, xe, ye, wide) in (
+                (1, 17, 61, 32, 128, None, False, False, False, False, 0, 0, False),          # one chunk, ragged tokens (1037)
+                (2, 40, 52, 64, 80, "relu", False, True, False, False, 16, 8, False),         # two chunks, N below one tile, views
+                (1, 37, 50, 96, 544, "gelu", True, True, True, True, 32, 16, False),          # three chunks, 544 = 4 x 128 + 32
+                (3, 28, 37, 256, 128, "softplus", False, False, False, True, 0, 0, False),
+                (1, 56, 74, 1024, 256, None, False, True, False, False, 0, 0, False),         # 32 chunks
+                (1, 33, 47, 128, 36, None, False, False, False, False, 0, 8, True)):          # N % 16 != 0; operands over twelve decades
+            w = torch.randn(N, K, generator=g) / K ** 0.5
+            b = torch.randn(N, generator=g)
+            sc = (0.5 + torch.rand(N, generator=g)) if scale else None
+            pw = pk.pack_conv(w.view(N, K, 1, 1), b, dtype=torch.float32, scale=sc).to(DEV)
+            assert pw.w3 is not None
+            M = B * H * W
+            xb = torch.randn(B, H, W, K + xe, generator=g)
+            if wide:
+                xb = xb * torch.logspace(-6, 6, K + xe)
+            xb = xb.to(DEV)
+            x = xb[..., xe // 2: xe // 2 + K]
+            r1 = torch.randn(B, H, W, pw.cout, generator=g).to(DEV) if res else None
+            r2 = torch.randn(B, H, W, pw.cout, generator=g).to(DEV) if res2 else None
+            xd = torch.relu(x.double()) if relu_in else x.double()
+            ref = xd.reshape(M, K) @ w.double().t().to(DEV) + b.double().to(DEV)
+            if act == "gelu":
+                ref = torch.nn.functional.gelu(ref)
+            elif act == "relu":
+                ref = torch.relu(ref)
+            elif act == "softplus":
+                ref = torch.nn.functional.softplus(ref)
+            if sc is not None:
+                ref = ref * sc.double().to(DEV)
+            if r1 is not None:
+                ref = ref + r1.double().reshape(M, -1)[:, :N]
+            if r2 is not None:
+                ref = ref + r2.double().reshape(M, -1)[:, :N]
+            den = max(1.0, float(ref.abs().max()))
+            es = []
+            for direct in (None, True):
+                yb = torch.full((B, H, W, pw.cout + ye), -7.0, device=DEV)
+                y = yb[..., ye // 2: ye // 2 + pw.cout]
+                o.conv(x, pw, y, act=act, relu_in=relu_in, res=r1, res2=r2, _direct=direct)
+                untouched = bool((yb[..., :ye // 2] == -7.0).all() and (yb[..., ye // 2 + pw.cout:] == -7.0).all())
+                e = float((y.reshape(M, -1)[:, :N].double() - ref).abs().max()) / den
+                es.append(e if untouched and torch.isfinite(y).all() else float("inf"))
+            from patchfusion_amd import hip_ops
+            route = hip_ops.HipOps._conv_plan(x, pw, y, 1, 0, act, relu_in, r1, r2, None)[0]
+            info.append(f"M={M} {K}->{N}: split {es[0]:.2e} f32 kernel {es[1]:.2e} route {route}")
+            worst = max(worst, es[0] if route == "s3_1x1" else float("inf"))
+    finally:
+        os.environ.pop("PF_CONV1X1_SPLIT3", None)
+        _switches_changed()
+    torch.cuda.synchronize()
+    return worst, 2e-6, "; ".join(info)
+
+
 def swin_ops(dt):
     errs = []
     for (B, H, W, C, heads) in ((1, 14, 19, 64, 32), (1, 28, 37, 64, 16), (2, 30, 25, 32, 8), (1, 13, 24, 256, 8), (1, 12, 12, 128, 8), (1, 17, 12, 256, 16), (1, 12, 24, 64, 8)):
@@ -971,8 +1037,8 @@ CHECKS = {
     "conv_split_n272_res_views": conv_split_n272_res_views, "conv_split_gemm_n544_inplace": conv_split_gemm_n544_inplace,
     "conv_gemm_vitl_linear_shape": conv_gemm_vitl_linear_shape, "conv_bf16_pp": conv_bf16_pp, "conv_dominant_launch": conv_dominant_launch,
     "conv_transpose": conv_transpose, "patch_embed_tokens": patch_embed_tokens, "layernorm": layernorm,
-    "vit_attention": vit_attention, "vit_attention_split": vit_attention_split, "gemm_split3": gemm_split3, "gemm_split3_persist": gemm_split3_persist, "vit_attention_split3": vit_attention_split3, "vit_attention_split3_v2": vit_attention_split3_v2, "swin_ops": swin_ops, "resize_ops": resize_ops, "roi_ops": roi_ops,
+    "vit_attention": vit_attention, "vit_attention_split": vit_attention_split, "gemm_split3": gemm_split3, "gemm_split3_persist": gemm_split3_persist, "conv1x1_split3": conv1x1_split3, "vit_attention_split3": vit_attention_split3, "vit_attention_split3_v2": vit_attention_split3_v2, "swin_ops": swin_ops, "resize_ops": resize_ops, "roi_ops": roi_ops,
     "conv_winograd": conv_winograd, "conv_winograd_subbatch": conv_winograd_subbatch, "conv_winograd_fused": conv_winograd_fused, "misc_ops": misc_ops, "bins_ops": bins_ops, "bins_tail": bins_tail, "stitch_ops": stitch_ops,
 }
-F32_ONLY = {"bins_ops", "bins_tail", "stitch_ops", "conv_winograd", "conv_winograd_subbatch", "conv_winograd_fused", "vit_attention_split", "gemm_split3", "gemm_split3_persist", "vit_attention_split3", "vit_attention_split3_v2"}
+F32_ONLY = {"conv1x1_split3", "bins_ops", "bins_tail", "stitch_ops", "conv_winograd", "conv_winograd_subbatch", "conv_winograd_fused", "vit_attention_split", "gemm_split3", "gemm_split3_persist", "vit_attention_split3", "vit_attention_split3_v2"}
 DTYPES = {"fp32": torch.float32, "bf16": torch.bfloat16}

@@ -83,7 +83,7 @@ def test_fused_winograd_kernel_resources_and_hand_counted_vmem(tmp_path):
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
-@pytest.mark.parametrize("src_name,min_kernels", [("gemm_split3.hip", 8), ("vit.hip", 14), ("attn_split3.hip", 3)])
+@pytest.mark.parametrize("src_name,min_kernels", [("gemm_split3.hip", 8), ("vit.hip", 14), ("attn_split3.hip", 3), ("conv1x1_split3.hip", 1), ("swin.hip", 10)])
 def test_split_precision_and_vit_kernels_have_no_scratch(tmp_path, src_name, min_kernels):
     """csrc/gemm_split3.hip (210 - 251 VGPRs: two 72-register fragment sets + accumulators at two waves per SIMD) and csrc/vit.hip (the split
     attention kernel runs three blocks per CU = 168 registers and spilled 12 B/lane in round 3): no scratch anywhere, at most 256 registers; csrc/attn_split3.hip (round 6: the pipelined attention holds Q, O, two S and two P

@@ -61,10 +61,10 @@ __device__ __forceinline__ void c1_xwrite(char* d, f32x4 xa, f32x4 xb, bool ok, 
 
 // BM = 64: 72 KiB of LDS, four waves -- TWO blocks per CU, so that one block's prologue (the first HBM round trip) and store tail run beside the
 // other's MFMAs; BM = 128: 96 KiB, eight waves, one block per CU (measured slower on every layer of the pass: nothing covers fill and drain).
-// WREG: the weight pieces travel through registers (global_load_dwordx4 + ds_write_b128, hand-counted like the token loads) instead of LDS-DMA:
-// a DMA piece stalls its wave's issue for ~95 cycles (m0 hand-over), six pieces per chunk and wave at BM = 64 are most of a chunk's MFMA time.
-template <int BM, bool WREG>
-__global__ __launch_bounds__(4 * BM) void conv1x1_split3_kernel(const pf_conv_params p, const bf16_t* __restrict__ w3, int w_rows, long w_bstride,
+// (Measured and NOT kept, round 6, profiles/r6_conv1x1_split3.md: the weight pieces through one or two register sets instead of LDS-DMA -- two chunks
+// of latency for W as well -- 0.89-0.95x; s_setprio around the MFMAs to de-phase the two blocks of a CU +-0; the 128-token tile 0.95x.)
+template <int BM>
+__global__ __launch_bounds__(4 * BM, 2) void conv1x1_split3_kernel(const pf_conv_params p, const bf16_t* __restrict__ w3, int w_rows, long w_bstride,
                                                                 int mt, int nt) {
   constexpr int WM = BM / WTM, NW = WM * WN;
   constexpr int XPLANE = BM * 64;                  // bytes of one token plane of a stage
@@ -129,29 +129,6 @@ __global__ __launch_bounds__(4 * BM) void conv1x1_split3_kernel(const pf_conv_pa
       wcur[i] += winc[i];
     }
   };
-  // WREG path: piece i of this wave waits in wr[i]; LDS destination = the DMA's (piece base + lane * 16)
-  f32x4 wr[WPW];
-  const int w_dst = 3 * XPLANE + lane * 16;                           // + stage + (pc >> 3) * WPLANE + (pc & 7) * 1024
-#define C1_WLOAD(KC)                                                                                            \
-  if constexpr (WREG) {                                                                                         \
-    const int kw_ = min((KC), nk - 1);                                                                          \
-    _Pragma("unroll") for (int i = 0; i < WPW; ++i) {                                                           \
-      const char* src_ = wcur[i] + (long)kw_ * winc[i];                                                         \
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(wr[i]) : "v"(src_) : "memory");                    \
-    }                                                                                                           \
-  }
-#define C1_WWRITE(STAGE_)                                                                                       \
-  if constexpr (WREG) {                                                                                         \
-    _Pragma("unroll") for (int i = 0; i < WPW; ++i) {                                                           \
-      const int pc = wave * WPW + i;                                                                            \
-      *reinterpret_cast<f32x4*>(smem + (STAGE_) * STAGE + w_dst + (pc >> 3) * WPLANE + (pc & 7) * 1024) = wr[i]; \
-    }                                                                                                           \
-  }
-#define C1_WTIE()                                                                                               \
-  if constexpr (WREG) {                                                                                         \
-    _Pragma("unroll") for (int i = 0; i < WPW; ++i) asm volatile("" : "+v"(wr[i]));                             \
-  }
-
   f32x4 acc[FN][FM];
 #pragma unroll
   for (int fn = 0; fn < FN; ++fn)
@@ -187,30 +164,19 @@ __global__ __launch_bounds__(4 * BM) void conv1x1_split3_kernel(const pf_conv_pa
   {                                                                        \
     const int kc_ = (KC), s_ = kc_ & 1;                                    \
     C1_WAIT(2, R0, R1);                                                    \
-    C1_WTIE()                                                              \
     c1_barrier();                                                          \
     if (kc_ + 1 < nk) {                                                    \
       C1_XWRITE(s_ ^ 1, R0, R1);                                           \
-      if constexpr (WREG) { C1_WWRITE(s_ ^ 1) } else wissue(s_ ^ 1);       \
+      wissue(s_ ^ 1);                                                      \
     }                                                                      \
-    C1_WLOAD(kc_ + 2)                                                      \
     C1_XLOAD(R0, R1, kc_ + 3)                                              \
     multiply(s_);                                                          \
   }
-  // prologue: stage 0 = chunk 0; X(1) in set b, X(2) in set a (WREG: W(1) in wr)
+  // prologue: stage 0 = chunk 0; X(1) in set b, X(2) in set a
   C1_XLOAD(xa0, xa1, 0)
-  if constexpr (WREG) {
-    C1_WLOAD(0)
-    C1_WAIT(0, xa0, xa1);
-    C1_WTIE()
-    C1_XWRITE(0, xa0, xa1);
-    C1_WWRITE(0)
-    C1_WLOAD(1)
-  } else {
-    wissue(0);
-    if constexpr (WPW == 6) { C1_WAIT(6, xa0, xa1); } else { C1_WAIT(3, xa0, xa1); }   // X(0) landed (the DMA pieces issued after it may still fly)
-    C1_XWRITE(0, xa0, xa1);
-  }
+  wissue(0);
+  if constexpr (WPW == 6) { C1_WAIT(6, xa0, xa1); } else { C1_WAIT(3, xa0, xa1); }   // X(0) landed (the DMA pieces issued after it may still fly)
+  C1_XWRITE(0, xa0, xa1);
   C1_XLOAD(xb0, xb1, 1)
   C1_XLOAD(xa0, xa1, 2)
   for (int kc = 0; kc < nk; kc += 2) {
@@ -219,7 +185,6 @@ __global__ __launch_bounds__(4 * BM) void conv1x1_split3_kernel(const pf_conv_pa
   }
 #undef C1_CHUNK
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(xa0), "+v"(xa1), "+v"(xb0), "+v"(xb1) :: "memory");   // drain the clamped tail loads
-  C1_WTIE()
 
   // ---- epilogue: bias -> act -> scale -> residual(s) -> float32 store ----
 #pragma unroll
@@ -277,24 +242,14 @@ extern "C" int pf_conv1x1_split3(const pf_conv_params* p, const void* w3, int w3
   if ((long)mt * nt >= (1L << 31)) return PF_ERR_ARG;
   constexpr int lds64 = 2 * (3 * 64 * 64 + 3 * WPLANE), lds128 = 2 * (3 * 128 * 64 + 3 * WPLANE);
   static const bool attr_ok =
-      hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_split3_kernel<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds64) == hipSuccess &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_split3_kernel<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds128) == hipSuccess;
+      hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_split3_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds64) == hipSuccess &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_split3_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds128) == hipSuccess;
   if (!attr_ok) return PF_ERR_LAUNCH;
-  static const bool attr_ok2 =
-      hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_split3_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds64) == hipSuccess &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_split3_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds128) == hipSuccess;
-  if (!attr_ok2) return PF_ERR_LAUNCH;
-  static const bool wreg = [] { const char* e = getenv("PF_C1_WREG"); return !(e && e[0] == '0'); }();      // 0 = weight pieces by LDS-DMA (A/B)
   const long w_bstride = (long)(p->Cin / 32) * w3_rows * 32;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const bf16_t* w = static_cast<const bf16_t*>(w3);
   const dim3 grid((unsigned)(mt * nt));
-  if (bm == 128) {
-    if (wreg) hipLaunchKernelGGL((conv1x1_split3_kernel<128, true>), grid, dim3(512), lds128, st, *p, w, w3_rows, w_bstride, mt, nt);
-    else hipLaunchKernelGGL((conv1x1_split3_kernel<128, false>), grid, dim3(512), lds128, st, *p, w, w3_rows, w_bstride, mt, nt);
-  } else {
-    if (wreg) hipLaunchKernelGGL((conv1x1_split3_kernel<64, true>), grid, dim3(256), lds64, st, *p, w, w3_rows, w_bstride, mt, nt);
-    else hipLaunchKernelGGL((conv1x1_split3_kernel<64, false>), grid, dim3(256), lds64, st, *p, w, w3_rows, w_bstride, mt, nt);
-  }
+  if (bm == 128) hipLaunchKernelGGL(conv1x1_split3_kernel<128>, grid, dim3(512), lds128, st, *p, w, w3_rows, w_bstride, mt, nt);
+  else hipLaunchKernelGGL(conv1x1_split3_kernel<64>, grid, dim3(256), lds64, st, *p, w, w3_rows, w_bstride, mt, nt);
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_LAUNCH;
 }

@@ -124,3 +124,37 @@ def test_split_gemm_kernel_choice_by_shape(monkeypatch):
     monkeypatch.setenv("PF_S3_PERSIST", "0")
     assert route(T, 544, 544, 36) == T128
     assert L.pf_gemm_split3_route(None, 256) == -1
+
+
+def test_float32_1x1_layers_carry_split_planes_and_route_by_shape(monkeypatch):
+    """round 6: pack_conv gives float32 1x1 layers with Cin % 32 == 0 the three bf16 planes of their weight (chunk-major, an exact split), and hip_ops
+    sends a call through csrc/conv1x1_split3.hip only where that kernel was measured to win (profiles/r6_conv1x1_split3.md)"""
+    monkeypatch.delenv("PF_CONV1X1_SPLIT3", raising=False)
+    w = torch.randn(80, 96, 1, 1) * torch.logspace(-3, 3, 96).view(1, 96, 1, 1)
+    bn = (torch.rand(80) + 0.5, torch.randn(80), torch.randn(80), torch.rand(80) + 0.5)
+    pw = pk.pack_conv(w, torch.randn(80), dtype=torch.float32, bn=bn)
+    assert pw.w3 is not None and pw.w3.dtype == torch.bfloat16 and tuple(pw.w3.shape) == (3, 3, 80, 32)
+    rows = pk.kmajor_to_rows(pw.w3)                                   # [3, rows, K]
+    assert bool((rows.double().sum(0) == pw.w[:, :96].double()).all())   # planes == the packed (BatchNorm-folded) float32 weight, exactly
+    assert _pack(64, 64).w3 is None and _pack(64, 40, k=1).w3 is None    # 3x3 layers and Cin % 32 != 0: no planes
+    assert pk.pack_conv(torch.randn(64, 64, 1, 1), None, dtype=torch.bfloat16).w3 is None
+    monkeypatch.setenv("PF_CONV1X1_SPLIT3", "0")
+    assert _pack(64, 64, k=1).w3 is None
+    monkeypatch.delenv("PF_CONV1X1_SPLIT3")
+    try:
+        hip_ops = importlib.import_module("patchfusion_amd.hip_ops")
+    except Exception as e:
+        pytest.skip(f"libpf_hip.so not built: {e}")
+
+    def want(M, cout, cin):
+        hip_ops.refresh_env()
+        return hip_ops._conv1x1_split3_wanted(M, _pack(cout, cin, k=1))
+    assert want(8 * 224 * 296, 128, 256) and want(66304, 1024, 256) and want(8 * 28 * 37, 1024, 1024) and want(33152, 128, 256)
+    assert not want(1037, 1024, 1024)              # the coarse branch's token count: less than two tiles per CU
+    assert not want(203056, 32, 128) and not want(203056, 96, 32) and not want(8 * 224 * 296, 4, 128)     # 32-channel sides, tiny heads
+    monkeypatch.setenv("PF_CONV1X1_SPLIT3", "2")
+    assert want(1037, 32, 32)
+    monkeypatch.setenv("PF_CONV1X1_SPLIT3", "0")
+    assert not want(8 * 224 * 296, 128, 256)
+    monkeypatch.delenv("PF_CONV1X1_SPLIT3")
+    hip_ops.refresh_env()

@@ -11,6 +11,8 @@
 #   pmc:<dtype>:<kernel>      three separate --pmc passes over `bench.py --roofline-only --dtype <dtype>` + tools/pmc_summary.py
 #   stats:<dtype>             rocprofv3 --kernel-trace --stats of the same roofline command
 #   headline                  all-16-tile parity of configs[2] (PF_HEADLINE_ALL=1)
+#   ab:<V1>+<V2>+...          tools/image_ab.py (interleaved whole-image A/B) over the variants; a variant is NAME=VAL[,NAME=VAL], the empty variant = default tree
+#   lib:<path>                PF_LIB_PATH for the stages that follow (A/B library builds: make -C patchfusion_amd/csrc variant NAME=.. DEFS=..; lib: resets)
 #   env:VAR=VALUE             export for the stages that follow (env:VAR= unsets)
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 mkdir -p gpurun_out; export TMPDIR=/tmp
@@ -36,6 +38,8 @@ for st in "$@"; do
          rm -f $O/${TAG}_pmc_*/p_kernel_trace.csv $O/${TAG}_pmc_*/*/*kernel_trace.csv ;;
     stats) ( timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats_$arg -o ro -- python bench.py --roofline-only --dtype $arg ) > $log 2> $log.err
            find $O/${TAG}_stats_$arg -name '*kernel_trace.csv' -delete ;;
+    ab) IFS='+' read -r -a vs <<< "$arg+"; ( timeout 1800 python tools/image_ab.py --steps 4 --rounds 3 "${vs[@]}" ) > $O/${TAG}_image_ab.md 2> $log ;;
+    lib) if [[ -z "$arg" ]]; then unset PF_LIB_PATH; else export PF_LIB_PATH="$PWD/$arg"; fi; echo "== $st"; continue ;;
     headline) ( PF_HEADLINE_ALL=1 timeout 900 python -m pytest tests/test_headline_parity_gpu.py -m gpu -x -q 2>&1 | tail -5 ) > $log 2>&1 ;;
     *) echo "unknown stage $st" ;;
   esac

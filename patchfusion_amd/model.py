@@ -169,8 +169,31 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
         self._pending_core_sd = [None, None]      # `core.` checkpoint tensors waiting for an external core provider (_load_branch)
         if config.load_branch:
             # patchfusion.py:105-109: each branch checkpoint is loaded with strict=True into its own sub-module
-            for prefix, path in zip(("coarse_branch.", "fine_branch."), config.pretrain_model):
-                self._load_branch(prefix, torch.load(path, map_location='cpu')['model_state_dict'])
+            # BOTH checkpoints pass their strict check before either is applied: a fine-branch checkpoint that fails must not leave the coarse
+            # branch's injected core provider already mutated (round-5 advisor finding)
+            loaded = [(prefix, torch.load(path, map_location='cpu')['model_state_dict'])
+                      for prefix, path in zip(("coarse_branch.", "fine_branch."), config.pretrain_model)]
+            for prefix, sd in loaded:
+                self._check_branch(prefix, sd)
+            for prefix, sd in loaded:
+                self._load_branch(prefix, sd)
+
+    def _check_branch(self, prefix, branch_sd):
+        """the strict key check of ``_load_branch`` alone (raises; mutates nothing)"""
+        want = [k[len(prefix):] for k in self.spec if k.startswith(prefix)]
+        wanted = set(want)
+        missing = [k for k in want if k not in branch_sd]
+        external_core = getattr(self.config[prefix[:-1]], "type", None) == 'ZoeDepth'
+        unexpected = [k for k in branch_sd if k not in wanted and not (external_core and k.startswith("core."))]
+        if missing or unexpected:
+            raise RuntimeError(f"Error(s) in loading state_dict for {prefix[:-1]}: Missing key(s): {missing[:8]}"
+                               f"{' ...' if len(missing) > 8 else ''}; Unexpected key(s): {unexpected[:8]}"
+                               f"{' ...' if len(unexpected) > 8 else ''}")
+
+    def drop_pending_core_weights(self):
+        """forget `core.` checkpoint tensors that are still waiting for a provider able to take them (a full CPU copy of a BEiT core otherwise
+        lives as long as the model); also done when the engine is built -- by then the providers in place are the ones that run"""
+        self._pending_core_sd = [None, None]
 
     def _load_branch(self, prefix, branch_sd):
         """``self.<branch>.load_state_dict(sd, strict=True)`` of the reference: missing / unexpected keys raise."""
@@ -342,6 +365,7 @@ class PatchFusion(nn.Module, PyTorchModelHubMixin):
             self._device = dev
             self._mask_cache = {}
             self._table_cache = {}
+            self.drop_pending_core_weights()                  # the providers in place are the ones that run
         return self._engine
 
     def _mask(self, shape):

@@ -152,6 +152,13 @@ def test_zoe_branch_checkpoint_with_core_weights_loads_through_the_configdict_ro
     with pytest.raises(RuntimeError, match="Missing"):
         PatchFusion(c2, ops=fake_ops, core_providers=untouched)
     assert not hasattr(untouched[1], "loaded")
+    assert not hasattr(untouched[0], "loaded")       # round-5 advisor finding: BOTH checkpoints are checked before EITHER provider is touched
+    # pending `core.` tensors (no provider could take them) can be dropped explicitly instead of living as long as the model
+    with pytest.warns(UserWarning, match="kept and handed to the provider"):
+        m2 = PatchFusion(c, ops=fake_ops, core_providers=(StandInCore(11), StandInCore(12)))
+    assert m2._pending_core_sd[0] is not None and m2._pending_core_sd[1] is not None
+    m2.drop_pending_core_weights()
+    assert m2._pending_core_sd == [None, None]
     got = m.state_dict()
     assert all(torch.equal(got[k], v) for k, v in sd.items() if k.startswith(("coarse_branch.", "fine_branch.")))
     # an unknown non-core key is still an error, like load_state_dict(strict=True)

@@ -99,17 +99,17 @@ def _bf16_pp_enabled():
 
 
 def _conv1x1_split3_wanted(M, pw):
-    """float32 1x1 layer through csrc/conv1x1_split3.hip (64 x 128 tiles, two blocks per CU) instead of the f32-MFMA implicit GEMM?  PF_CONV1X1_SPLIT3:
-    0 = never, 2 = wherever the planes exist, 1 (default) = the measured rule (profiles/r6_conv1x1_split3.md: 1.16-1.47x on every layer of the pass
-    with at least 64 input and 64 output channels and two tiles per CU; 0.7-1.1x on the 32-channel layers, where a 128-wide channel tile
-    multiplies zeros and a K chunk is the whole layer)."""
+    """float32 1x1 layer through csrc/conv1x1_split3.hip (persistent walk of 64 x 128 tiles, two blocks per CU) instead of the f32-MFMA implicit GEMM?
+    PF_CONV1X1_SPLIT3: 0 = never, 2 = wherever the planes exist, 1 (default) = the measured rule (profiles/r6_conv1x1_split3.md: 1.23-1.55x on every layer
+    of the pass with at least 64 output channels and two tiles per CU, incl. the 32 -> 96 / 128 linears of the first G2L level; 0.78x on 128 -> 32 and
+    1.06x on 32 -> 32, where a 128-wide channel tile multiplies zeros)."""
     mode = _env("PF_CONV1X1_SPLIT3", "1")
     if mode == "0":
         return False
     if mode == "2":
         return True
     tiles = -(-M // 64) * -(-pw.cout // 128)
-    return tiles >= 512 and pw.cout >= 64 and pw.cin >= 64
+    return tiles >= 512 and pw.cout >= 64
 
 
 def _split3_three_step(pw):

@@ -40,6 +40,16 @@ def _err(a, b):
     return float((a - b).abs().max() / max(1.0, float(b.abs().max())))
 
 
+_FLUSH = []
+
+
+def _flush_caches():
+    """overwrite 1 GiB: L2 (4 MiB per XCD) and the 256 MiB memory-side cache forget the operands of the next launch"""
+    if not _FLUSH:
+        _FLUSH.append(torch.empty(256 * 2 ** 20, dtype=torch.float32, device=DEV))
+    _FLUSH[0].add_(1.0)
+
+
 def _conv_case(dtype, B, H, W, cin, cout, k, stride=1, pad=0, act=None, relu_in=False, res=False, res2=False, bias=True,
                scale=False, x_extra=0, y_extra=0, out_f32=False, inplace=False, cin_real=None, seed=0):
     cin_real = cin_real or cin
@@ -760,14 +770,30 @@ def conv1x1_split3(dt):
             if r2 is not None:
                 ref = ref + r2.double().reshape(M, -1)[:, :N]
             den = max(1.0, float(ref.abs().max()))
-            es = []
-            for direct in (None, True):
+            es, first = [], None
+            # (None, slots): the split kernel with PF_C1_SLOTS token-tile slots per channel tile -- default grid, then 3 and 1 slots (every block walks
+            # many tiles: the persistent chunk stream across tile boundaries, ragged last tile) -- all bit-identical; (True, None): the f32-MFMA kernel
+            for direct, slots in ((None, None), (None, "3"), (None, "1"), (True, None)):
+                if slots is None:
+                    os.environ.pop("PF_C1_SLOTS", None)
+                else:
+                    os.environ["PF_C1_SLOTS"] = slots
                 yb = torch.full((B, H, W, pw.cout + ye), -7.0, device=DEV)
                 y = yb[..., ye // 2: ye // 2 + pw.cout]
+                _flush_caches()      # cold operands: a hand-counted wait that leaves a needed piece in flight shows on the FIRST touch, not on warm re-runs
                 o.conv(x, pw, y, act=act, relu_in=relu_in, res=r1, res2=r2, _direct=direct)
                 untouched = bool((yb[..., :ye // 2] == -7.0).all() and (yb[..., ye // 2 + pw.cout:] == -7.0).all())
                 e = float((y.reshape(M, -1)[:, :N].double() - ref).abs().max()) / den
-                es.append(e if untouched and torch.isfinite(y).all() else float("inf"))
+                if direct is None:
+                    if first is None:
+                        first = yb.clone()
+                    elif not bool((yb == first).all()):
+                        e = float("inf")                 # the tile walk changed the numbers
+                if slots is None:
+                    es.append(e if untouched and torch.isfinite(y).all() else float("inf"))
+                elif not (untouched and e < float("inf")):
+                    es[0] = float("inf")
+            os.environ.pop("PF_C1_SLOTS", None)
             from patchfusion_amd import hip_ops
             route = hip_ops.HipOps._conv_plan(x, pw, y, 1, 0, act, relu_in, r1, r2, None)[0]
             info.append(f"M={M} {K}->{N}: split {es[0]:.2e} f32 kernel {es[1]:.2e} route {route}")

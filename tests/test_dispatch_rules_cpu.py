@@ -151,7 +151,8 @@ def test_float32_1x1_layers_carry_split_planes_and_route_by_shape(monkeypatch):
         return hip_ops._conv1x1_split3_wanted(M, _pack(cout, cin, k=1))
     assert want(8 * 224 * 296, 128, 256) and want(66304, 1024, 256) and want(8 * 28 * 37, 1024, 1024) and want(33152, 128, 256)
     assert not want(1037, 1024, 1024)              # the coarse branch's token count: less than two tiles per CU
-    assert not want(203056, 32, 128) and not want(203056, 96, 32) and not want(8 * 224 * 296, 4, 128)     # 32-channel sides, tiny heads
+    assert want(203056, 96, 32) and want(203056, 128, 32)          # the 32 -> 96 / 128 linears of the first G2L level
+    assert not want(203056, 32, 128) and not want(8 * 392 * 518, 32, 32) and not want(8 * 224 * 296, 4, 128)     # fewer than 64 output channels
     monkeypatch.setenv("PF_CONV1X1_SPLIT3", "2")
     assert want(1037, 32, 32)
     monkeypatch.setenv("PF_CONV1X1_SPLIT3", "0")

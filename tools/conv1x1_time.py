@@ -18,6 +18,29 @@ SHAPES = ((8 * 224 * 296, 256, 128, "relu", 4), (8 * 224 * 296, 256, 256, None, 
           (8 * 112 * 148, 256, 256, None, 2), (8 * 112 * 148, 128, 128, "relu", 8), (8 * 28 * 37, 1024, 512, None, 2), (8 * 56 * 74, 256, 128, "relu", 4),
           (203056, 32, 96, None, 2), (203056, 32, 128, "gelu", 2), (203056, 128, 32, None, 2), (8 * 392 * 518, 32, 32, None, 2))
 g = torch.Generator().manual_seed(0)
+if len(sys.argv) > 1 and sys.argv[1] == "decomp":
+    # timing decomposition with the PF_C1_DBG build (make -C patchfusion_amd/csrc variant NAME=c1dbg DEFS=-DPF_C1_DBG; PF_LIB_PATH=.../libpf_c1dbg.so):
+    # parts of the kernel switched off one at a time (results wrong by construction)
+    names = {0: "full", 1: "no MFMA", 2: "no token loads", 4: "no weight DMA", 8: "no split / plane writes", 16: "no fragment reads (one stage re-read)",
+             32: "no barrier", 6: "no loads at all", 14: "no loads, no split", 15: "MFMA off + no loads + no split", 30: "only MFMA + barrier (no loads, split, frag re-reads)"}
+    print("| layer | " + " | ".join(names.values()) + " |")
+    print("|---|" + "---|" * len(names))
+    for (M, K, N, act, n) in SHAPES[:2] + SHAPES[4:5]:
+        w = torch.randn(N, K, 1, 1, generator=g) / K ** 0.5
+        pw = pk.pack_conv(w, torch.randn(N, generator=g), dtype=torch.float32).to("cuda")
+        x = torch.randn(1, 1, M, K, generator=g).to("cuda")
+        y = torch.empty(1, 1, M, N, device="cuda")
+        row = []
+        for bits in names:
+            os.environ["PF_C1_DBG"] = str(bits)
+            best = 1e9
+            for rnd in range(3):
+                t = ops.conv(x, pw, y, act=act, _timed=10, _direct=False)
+                if rnd:
+                    best = min(best, t)
+            row.append(best * 1e3)
+        print(f"| {M} x {K}->{N} | " + " | ".join(f"{t:.1f}" for t in row) + " |")
+    sys.exit(0)
 print("| tokens | layer | launches / image | f32 MFMA us (TF/s) | split us (TF/s, of 416.7) | speed-up | ms / image saved |")
 print("|---|---|---|---|---|---|---|")
 tot_a = tot_b = 0.0

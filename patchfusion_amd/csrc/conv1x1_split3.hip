@@ -21,8 +21,8 @@
 // in flight under the last MFMAs and the epilogue of tile t.  nslots == mt is the one-tile-per-block form (PF_C1_PERSIST=0).
 // Pipeline, ONE barrier per chunk g: wait for W(g) (issued one chunk ago) and X(g) (two chunks ago) -- the pieces of X(g+1), younger than both, stay in
 // flight; the barrier publishes them and retires the reads of chunk g-1; issue W(g+1) and X(g+2) into the slots chunk g-1 left; read the fragments,
-// split the token fragments, multiply; after a tile's last chunk its epilogue (as pf_conv: (act(v + bias) * scale) + res + res2, float32 out) --
-// its stores share the counter with the DMA and retire out of order with it, so the first wait after an epilogue is vmcnt(0).
+// split the token fragments, multiply; after a tile's last chunk its epilogue (as pf_conv: (act(v + bias) * scale) + res + res2, float32 out).
+// RULE for a hand-counted wait: what may stay in flight must be of the same kind as, and younger than, everything the wait is for.
 #include <cstdlib>
 #include "pf_common.h"
 #include "../../include/pf_hip.h"
@@ -242,12 +242,12 @@ __global__ __launch_bounds__(4 * BM, 2) void conv1x1_split3_kernel(const pf_conv
   wissue(0);
   if (total > 1) xissue(1);
   int ck = 0, ct = 0;
-  bool after_epi = false;
   for (int g = 0, xs = 0; g < total; ++g) {
-    // queue, oldest first:  ... X(g) | W(g) | X(g+1)  -- the last XPW pieces may stay in flight (none were issued when g + 1 == total)
-    if (after_epi || g + 1 >= total || C1_DBG(64)) c1_vm_wait<0>();
+    // queue, oldest first:  ... X(g) | W(g) | X(g+1) [| the stores of an epilogue]: the XPW pieces of X(g+1) may stay in flight (none were issued when
+    // g + 1 == total).  Safe with stores behind them too: the pieces retire in issue order among themselves, so while a needed piece is out so are both
+    // pieces of X(g+1) and the count is above XPW whatever the stores do (they retire out of order with loads; late ones only make the wait longer).
+    if (g + 1 >= total || C1_DBG(64)) c1_vm_wait<0>();
     else c1_vm_wait<XPW>();
-    after_epi = false;
     if (!C1_DBG(32)) c1_barrier();
     if (g + 1 < total) wissue((g + 1) & 1);
     if (g + 2 < total) xissue(xs == 0 ? 2 : xs - 1);                  // stage (g + 2) % 3
@@ -256,7 +256,6 @@ __global__ __launch_bounds__(4 * BM, 2) void conv1x1_split3_kernel(const pf_conv
     if (ck + 1 < nk) ++ck;
     else {
       epilogue((mslot + ct * nslots) * BM);
-      after_epi = true;
       ck = 0;
       ++ct;
     }

@@ -85,6 +85,10 @@ def work(name, a, k):
             tag = (f" [winograd F{m} FUSED kernel, f32 MFMA]" if fused else
                    f" [winograd F{m}: 3 steps, {'split-precision GEMM on the bf16 MFMA' if split else 'f32 MFMA GEMM'}; time incl. transforms]")
             return "flop", own, desc + tag + f" (direct-conv equivalent x{fl / own:.2f})", (SPLIT_PEAK if split else None)
+        if (pw.w3 is not None and x4.dtype == torch.float32 and pw.KH == 1 and pw.KW == 1 and k.get("stride", 1) == 1 and k.get("pad", 0) == 0 and s == 1 and
+                hip_ops._conv1x1_split3_wanted(x4.shape[0] * x4.shape[1] * x4.shape[2], pw)):
+            # float32 1x1 layer on the bf16 matrix cores, activations split in the kernel (csrc/conv1x1_split3.hip)
+            return "flop", fl, desc + " [split-precision bf16x3, float32 in / out]", SPLIT_PEAK
         return "flop", fl, desc
     if name == "conv_split3":
         x3, pw, y = a[0], a[1], a[2]

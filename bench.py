@@ -378,23 +378,27 @@ def roofline_attention(dev):
     q3 = torch.empty(3, B * S, 3 * D, dtype=torch.bfloat16, device=dev)
     ops.split3(qkv, q3)
     out = torch.empty(3, D // 32, B * S, 32, dtype=torch.bfloat16, device=dev)
-    for _ in range(3):
-        ops.vit_attention(q3, out, B, S, Hh)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n = 50
-    e0.record()
+    # three rounds of 40 launches, the MEDIAN round reported (all three printed): a single 50-launch average after three warm-up launches sat on the
+    # clock ramp of a chip that had just idled through the operand set-up -- 221 / 235 us in two processes against 191-199 us in tools/attn_split3_time.py
+    n, rounds = 40, []
     for _ in range(n):
         ops.vit_attention(q3, out, B, S, Hh)
-    e1.record()
-    e1.synchronize()
-    ms = e0.elapsed_time(e1) / n
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            ops.vit_attention(q3, out, B, S, Hh)
+        e1.record()
+        e1.synchronize()
+        rounds.append(e0.elapsed_time(e1) / n)
+    ms = sorted(rounds)[1]
     flops = 4.0 * B * Hh * S * S * 64
     ach = flops / (ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS["bf16"] / 6.0
     return {"kernel": "vit_attention_split3_pipe_kernel (32 x 32 x 16 bf16 MFMAs x 6 per float32 product, QK / softmax / PV of three consecutive 32-key blocks overlapped "
                       f"in every wave; LDS-DMA K / V rings, transposing V reads) at {B} tiles x {Hh} heads x {S} tokens (24 such launches per tile batch)",
             "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4), "us_per_launch": round(ms * 1e3, 1),
-            "flops_per_launch": flops}
+            "rounds_us": [round(r * 1e3, 1) for r in rounds], "flops_per_launch": flops}
 
 
 def roofline(dtype, dev, gemm_only=False):

@@ -9,9 +9,11 @@
 //   D[n][m] = sum_k W[n][k] X[m][k]     MFMA A = weight rows, B = token rows; a lane's four accumulator registers = four consecutive channels
 //                                        of one token (float4 stores along the channel axis), exactly as in gemm_split3.hip / igemm.hip
 // Tile 64 (or 128) tokens x 128 channels, K chunks of 32, four (eight) waves of 32 x 64 (FM = 2, FN = 4: 48 MFMAs per chunk and wave).
-// LDS: a ring of THREE float32 token stages (BM rows x 128 B; 16-byte slot s of row r at s ^ ((r >> 1) & 7)) and TWO weight stages (3 planes x 128
-// rows x 64 B; slot g of row r at g ^ ((r >> 1) & 3)): every ds_read_b128 of a fragment touches 16 distinct 16-byte positions of the 256-byte bank
-// window.  The DMA writes lane-linearly, so both swizzles are applied on the source side.
+// LDS: a ring of THREE float32 token stages (BM rows x 128 B; the float4 k = 4 u .. 4 u + 3 of row r in stored slot sg = (u >> 1) + 4 (u & 1) at
+// sg ^ ((r >> 1) & 7)) and TWO weight stages (3 planes x 128 rows x 64 B; slot g of row r at g ^ ((r >> 1) & 3)): every ds_read_b128 of a fragment touches
+// 16 distinct 16-byte positions of the 256-byte bank window in each of the hardware's 16-lane groups -- which pair even-g lanes of rows {0-3, 12-15} with
+// odd-g lanes of rows {4-11}: the natural slot order u = 2 g + h collides there (tests/test_conv1x1_lds_layout_cpu.py replays both).  The DMA writes
+// lane-linearly, so both swizzles are applied on the source side.
 // EVERY load is an LDS-DMA piece, so the hand-counted s_waitcnt vmcnt(N) sees ONE in-order queue.  (The first form of this kernel loaded the tokens
 // into registers -- split by the loading thread, planes written to LDS -- beside the weights' DMA pieces, with vmcnt(2) leaving the younger register
 // set in flight: fast, and WRONG on cold caches -- DMA pieces and register loads do not retire in issue order with respect to each other, the
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(4 * BM, 2) void conv1x1_split3_kernel(const pf_conv
   const unsigned smem_base = c1_lds_addr(smem);
 
   // ---- token loader: wave w moves pieces XPW w, XPW w + 1 of the BM / 8 (8 rows x 128 B each); lane L -> row 8 piece + (L >> 3), physical slot
-  // L & 7 = logical slot ^ ((row >> 1) & 7).  Rows beyond M read the zero page.  (lt, lk) = tile of the walk and chunk of the NEXT token issue.
+  // L & 7 = stored slot ^ ((row >> 1) & 7).  Rows beyond M read the zero page.  (lt, lk) = tile of the walk and chunk of the NEXT token issue.
   int lt = 0, lk = 0;
   const char* xcur[XPW];
   int xoff[XPW];                                                      // byte offset of the lane's source inside a token row's chunk
@@ -87,7 +89,8 @@ __global__ __launch_bounds__(4 * BM, 2) void conv1x1_split3_kernel(const pf_conv
   for (int i = 0; i < XPW; ++i) {
     const int pc = wave * XPW + i, row = pc * 8 + (lane >> 3);
     xrow[i] = row;
-    xoff[i] = (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+    const int sg = (lane & 7) ^ ((row >> 1) & 7);                      // stored slot -> the float4 k = 4 u .. 4 u + 3 it holds: u = 2 (sg & 3) + (sg >> 2)
+    xoff[i] = ((((sg & 3) << 1) | (sg >> 2)) << 4);
   }
   auto xtile = [&](int t) __attribute__((always_inline)) {            // the lane's source rows of tile t of the walk
 #pragma unroll
@@ -148,8 +151,9 @@ __global__ __launch_bounds__(4 * BM, 2) void conv1x1_split3_kernel(const pf_conv
     for (int fm = 0; fm < FM; ++fm) acc[fn][fm] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fg = lane >> 4;
-  // token fragment: row wm * 32 + fm * 16 + fr, logical 16-byte slots 2 fg and 2 fg + 1 (k = 8 fg .. 8 fg + 7); the swizzle term is per lane
-  const int x_off = (wm * WTM + fr) * 128 + (((2 * fg) ^ ((fr >> 1) & 7)) << 4);        // + fm * 2048; second half at ^ 16
+  // token fragment: row wm * 32 + fm * 16 + fr, k = 8 fg .. 8 fg + 3 in stored slot fg, k = 8 fg + 4 .. 8 fg + 7 in stored slot fg + 4; the swizzle term
+  // is per lane
+  const int x_off = (wm * WTM + fr) * 128 + ((fg ^ ((fr >> 1) & 7)) << 4);              // + fm * 2048; second half at ^ 64
   const int w_off = (wn * WTN + fr) * 64 + ((fg ^ ((fr >> 1) & 3)) << 4);               // + plane * BN * 64 + fn * 1024
   // the block's channel tile never changes: bias in registers for the whole walk
   float4 bias_r[FN];
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(4 * BM, 2) void conv1x1_split3_kernel(const pf_conv
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm) {
       const float4 a = *reinterpret_cast<const float4*>(XS + x_off + fm * 2048);
-      const float4 b = *reinterpret_cast<const float4*>(XS + (x_off ^ 16) + fm * 2048);
+      const float4 b = *reinterpret_cast<const float4*>(XS + (x_off ^ 64) + fm * 2048);
       float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
       if (C1_DBG(8)) {
         fx[0][fm] = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));

@@ -1,3 +1,6 @@
+"""GPU probe: pf_conv1x1_split3 on FRESHLY uploaded operands (cold L2 / memory-side cache) at a few small shapes, default grid and 3 / 1 tile slots, against
+float64 -- the script that showed the register-prefetch form of the kernel to be wrong on its first launch (whole token rows off by O(1)) and exact on warm
+re-runs (profiles/r6_conv1x1_split3.md).  PF_LIB_PATH=.../libpf_c1dbg.so PF_C1_DBG=64 forces every wait to vmcnt(0).  usage: python tools/c1_debug.py"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["PF_CONV1X1_SPLIT3"] = "2"

@@ -25,6 +25,9 @@
 // flight; the barrier publishes them and retires the reads of chunk g-1; issue W(g+1) and X(g+2) into the slots chunk g-1 left; read the fragments,
 // split the token fragments, multiply; after a tile's last chunk its epilogue (as pf_conv: (act(v + bias) * scale) + res + res2, float32 out).
 // RULE for a hand-counted wait: what may stay in flight must be of the same kind as, and younger than, everything the wait is for.
+// (Measured and NOT kept, profiles/r6_conv1x1_split3.md: the 128 x 128-tile persistent PING-PONG kernel of gemm_split3.hip with a float32-token stage and the
+// split in a wave's load phase -- correct, and 0.8x of this kernel on every layer: DMA issue + split + fragment reads do not fit beside the partner
+// group's 48 MFMAs at K = 128 .. 1024.)
 #include <cstdlib>
 #include "pf_common.h"
 #include "../../include/pf_hip.h"

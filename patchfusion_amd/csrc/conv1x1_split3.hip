@@ -28,6 +28,7 @@
 // (Measured and NOT kept, profiles/r6_conv1x1_split3.md: the 128 x 128-tile persistent PING-PONG kernel of gemm_split3.hip with a float32-token stage and the
 // split in a wave's load phase -- correct, and 0.8x of this kernel on every layer: DMA issue + split + fragment reads do not fit beside the partner
 // group's 48 MFMAs at K = 128 .. 1024.)
+#include <atomic>
 #include <cstdlib>
 #include "pf_common.h"
 #include "../../include/pf_hip.h"
@@ -291,7 +292,7 @@ extern "C" int pf_conv1x1_split3(const pf_conv_params* p, const void* w3, int w3
   // PF_C1_BM = 64 | 128 forces a token tile (A/B, tests); default 64 (two blocks per CU).  PF_C1_PERSIST=0: one tile per block (A/B, tests).
   static const int force = [] { const char* e = getenv("PF_C1_BM"); return e ? atoi(e) : 0; }();
   static const bool persist = [] { const char* e = getenv("PF_C1_PERSIST"); return !(e && e[0] == '0'); }();
-  static const int cus = [] { int dev = 0, n = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+  static const int cus = [] { int d = 0, n = 0; hipGetDevice(&d); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 0 ? n : 256; }();
   const int bm = force == 128 ? 128 : 64;
   const int mt = (int)((M + bm - 1) / bm), nt = (p->Cout + BN - 1) / BN;
   if ((long)mt * nt >= (1L << 31)) return PF_ERR_ARG;
@@ -307,10 +308,17 @@ extern "C" int pf_conv1x1_split3(const pf_conv_params* p, const void* w3, int w3
     if (v > 0) nslots = v < mt ? v : mt;
   }
   constexpr int lds64 = 3 * 64 * 128 + 2 * WSTAGE, lds128 = 3 * 128 * 128 + 2 * WSTAGE;
-  static const bool attr_ok =
-      hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_split3_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds64) == hipSuccess &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_split3_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds128) == hipSuccess;
-  if (!attr_ok) return PF_ERR_LAUNCH;
+  // (the attribute belongs to a device: one bit per device, as in gemm_split3.hip -- a process that drives several GPUs sets it on each)
+  static std::atomic<unsigned long long> attr_done{0};
+  int dev = 0;
+  hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_split3_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds64) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_split3_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds128) != hipSuccess)
+      return PF_ERR_LAUNCH;
+    attr_done.fetch_or(bit, std::memory_order_release);
+  }
   const long w_bstride = (long)(p->Cin / 32) * w3_rows * 32;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const bf16_t* w = static_cast<const bf16_t*>(w3);

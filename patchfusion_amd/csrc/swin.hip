@@ -3,8 +3,8 @@
 // head_dim is tiny here (2..32) -- MFMA-hostile -- so the attention runs on the VALU with K/V of one
 // (window, head) in LDS (broadcast reads) and one query per thread; it is HBM/LDS bound.
 #include "pf_common.h"
+#include <atomic>
 #include <cstdlib>
-#include <mutex>
 #include "../../include/pf_hip.h"
 
 namespace {
@@ -335,12 +335,16 @@ int launch_wattn_mfma(const float* qkv, float* out, const float* bt, int B, int 
   constexpr int NW = 9;
   constexpr int NH = 32 / HD;
   const int lds = (3 * WTOK * 36 + NH * 529 + 2 * WTOK) * 4;
-  static std::once_flag once;
-  static bool attr_ok = false;
-  std::call_once(once, [&] {
-    attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(swin_window_attention_mfma_kernel<HD, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
-  });
-  if (!attr_ok) return PF_ERR_LAUNCH;
+  // (the attribute belongs to a device: one bit per device and head_dim, so that a process that drives several GPUs sets it on each)
+  static std::atomic<unsigned long long> attr_done{0};
+  int dev = 0;
+  hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(swin_window_attention_mfma_kernel<HD, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return PF_ERR_LAUNCH;
+    attr_done.fetch_or(bit, std::memory_order_release);
+  }
   dim3 grid(B * (Hp / WIN) * (Wp / WIN), C / 32);
   hipLaunchKernelGGL((swin_window_attention_mfma_kernel<HD, NW>), grid, dim3(NW * 64), lds, st, qkv, out, bt, Hp, Wp, C, heads, shift);
   return ok();

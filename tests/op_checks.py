@@ -741,7 +741,9 @@ def conv1x1_split3(dt):
                 (1, 37, 50, 96, 544, "gelu", True, True, True, True, 32, 16, False),          # three chunks, 544 = 4 x 128 + 32
                 (3, 28, 37, 256, 128, "softplus", False, False, False, True, 0, 0, False),
                 (1, 56, 74, 1024, 256, None, False, True, False, False, 0, 0, False),         # 32 chunks
-                (1, 33, 47, 128, 36, None, False, False, False, False, 0, 8, True)):          # N % 16 != 0; operands over twelve decades
+                (1, 33, 47, 128, 36, None, False, False, False, False, 0, 8, True),           # N % 16 != 0; operands over twelve decades
+                (1, 1, 5, 64, 64, "relu", True, False, False, False, 0, 0, False),             # five tokens: one partial tile, half a channel tile (zero-page weight rows)
+                (1, 181, 182, 64, 64, None, False, True, False, False, 0, 0, False)):          # 32 942 tokens: the DEFAULT grid already walks two tiles per block
             w = torch.randn(N, K, generator=g) / K ** 0.5
             b = torch.randn(N, generator=g)
             sc = (0.5 + torch.rand(N, generator=g)) if scale else None

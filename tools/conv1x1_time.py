@@ -18,6 +18,17 @@ SHAPES = ((8 * 224 * 296, 256, 128, "relu", 4), (8 * 224 * 296, 256, 256, None, 
           (8 * 112 * 148, 256, 256, None, 2), (8 * 112 * 148, 128, 128, "relu", 8), (8 * 28 * 37, 1024, 512, None, 2), (8 * 56 * 74, 256, 128, "relu", 4),
           (203056, 32, 96, None, 2), (203056, 32, 128, "gelu", 2), (203056, 128, 32, None, 2), (8 * 392 * 518, 32, 32, None, 2))
 g = torch.Generator().manual_seed(0)
+if len(sys.argv) > 1 and sys.argv[1] == "launch":
+    # N launches of ONE layer through the split route (tools/kernel_pmc.sh): python tools/conv1x1_time.py launch N tokens Cin Cout
+    n, M, K, N = (int(v) for v in sys.argv[2:6])
+    w = torch.randn(N, K, 1, 1, generator=g) / K ** 0.5
+    pw = pk.pack_conv(w, torch.randn(N, generator=g), dtype=torch.float32).to("cuda")
+    x = torch.randn(1, 1, M, K, generator=g).to("cuda")
+    y = torch.empty(1, 1, M, N, device="cuda")
+    for _ in range(n):
+        ops.conv(x, pw, y, act="relu", _direct=False)
+    torch.cuda.synchronize()
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "decomp":
     # timing decomposition with the PF_C1_DBG build (make -C patchfusion_amd/csrc variant NAME=c1dbg DEFS=-DPF_C1_DBG; PF_LIB_PATH=.../libpf_c1dbg.so):
     # parts of the kernel switched off one at a time (results wrong by construction)

@@ -9,6 +9,16 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from patchfusion_amd.hip_ops import ops        # noqa: E402
 
+if len(sys.argv) > 1 and sys.argv[1] == "launch":
+    # N launches of ONE level (tools/kernel_pmc.sh): python tools/swin_attn_time.py launch N Hp Wp C heads
+    n, Hp, Wp, C, heads = (int(v) for v in sys.argv[2:7])
+    qkv = torch.randn(Hp * Wp, 3 * C, device="cuda")
+    bt = torch.randn(529, heads, device="cuda") * 0.5
+    out = torch.empty(Hp * Wp, C, device="cuda")
+    for _ in range(n):
+        ops.swin_window_attention(qkv, out, bt, 1, Hp, Wp, C, heads, 6)
+    torch.cuda.synchronize()
+    sys.exit(0)
 mode = "VALU kernel (PF_SWIN_MFMA=0)" if os.environ.get("PF_SWIN_MFMA", "1") == "0" else "f32-MFMA kernel (default)"
 print(f"| window attention, {mode} | us | algorithmic GB/s | of 8 TB/s | useful TF/s |")
 print("|---|---|---|---|---|")
